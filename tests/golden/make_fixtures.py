@@ -1,0 +1,213 @@
+"""Generate golden fixtures by importing the reference's runnable leaf modules.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box never sees the
+reference.  Writes small .npz/.json files next to this script:
+
+  manifest_unet.json / manifest_generator.json  state_dict key -> shape of the reference modules
+  schedule.npz        GaussianDiffusion schedule buffers (reference diffusion/diffusion.py:46-87)
+  unet_fwd.npz        UNet1DConditionModel forward, seeded weights, float + integer timesteps,
+                      T multiple of 8 and not; a few intermediate activations
+  solver_toy.npz      DPM-Solver++(2M) / UniPC-bh2 trajectories with an analytic eps model
+  sampler.npz         GaussianDiffusion.forward(infer=True) for dpm-solver/unipc/ddim/pndm/ddpm
+  vocoder.npz         Generator forward (synthetic h), weight-norm checkpoint
+
+Weights always come from the build-owned seeded initialiser (lds/init_weights.py) loaded
+into the reference modules with load_state_dict, so they can be regenerated anywhere.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "latent-diffusion-speech_amd"))
+sys.path.insert(1, "/root/reference")
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+
+from lds import arch, init_weights  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+# import-only placeholders for packages the container lacks; the decoder
+# classes we run never touch them.
+_vq = types.ModuleType("vector_quantize_pytorch")
+_vq.VectorQuantize = object
+sys.modules.setdefault("vector_quantize_pytorch", _vq)
+_ta = types.ModuleType("torchaudio")
+_tat = types.ModuleType("torchaudio.transforms")
+_ta.transforms = _tat
+for n in ("Spectrogram", "Resample", "MelSpectrogram"):
+    setattr(_tat, n, object)
+sys.modules.setdefault("torchaudio", _ta)
+sys.modules.setdefault("torchaudio.transforms", _tat)
+
+from diffusion.diffusion import GaussianDiffusion  # noqa: E402  (reference)
+from diffusion.unet1d.unet_1d_condition import UNet1DConditionModel  # noqa: E402
+from diffusion import dpm_solver_pytorch, uni_pc  # noqa: E402
+from encoder.hifi_vaegan.modules.models import Generator  # noqa: E402
+
+SEED_W = 0
+
+
+def tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_unet():
+    cfg = arch.unet_config()
+    m = UNet1DConditionModel(
+        in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+        block_out_channels=cfg["block_out_channels"], norm_num_groups=8,
+        cross_attention_dim=cfg["block_out_channels"], attention_head_dim=8,
+        only_cross_attention=True, layers_per_block=2, resnet_time_scale_shift="scale_shift")
+    shapes = arch.unet_param_shapes(cfg)
+    sd = {k: tt(v) for k, v in init_weights.init_state(shapes, SEED_W).items()}
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return cfg, m
+
+
+def main():
+    cfg, unet = build_unet()
+    man = {k: list(v.shape) for k, v in unet.state_dict().items()}
+    json.dump(man, open(os.path.join(HERE, "manifest_unet.json"), "w"), indent=0)
+
+    gd = GaussianDiffusion(unet, out_dims=80)
+    sched = {k: v.numpy() for k, v in gd.state_dict().items() if not k.startswith("denoise_fn.")}
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **sched)
+    json.dump({k: list(v.shape) for k, v in gd.state_dict().items() if not k.startswith("denoise_fn.")},
+              open(os.path.join(HERE, "manifest_diffusion_buffers.json"), "w"), indent=0)
+
+    # ---------------- UNet forward -------------------------------------------------
+    out = {}
+    taps = ["conv_in", "down_blocks.0.resnets.0", "down_blocks.0.attentions.0", "down_blocks.0",
+            "down_blocks.1.resnets.0", "mid_block", "up_blocks.0", "up_blocks.3.resnets.0", "time_embedding"]
+    mods = dict(unet.named_modules())
+    for case, (B, T, tvals) in {
+        "a": (2, 64, [979.02, 19.98]),          # float, non-integer solver times, per-sample
+        "b": (1, 40, [500.0]),                  # T % 8 != 0 -> forward_upsample_size path
+        "c": (2, 16, None),                     # integer (int64) DDPM timesteps
+    }.items():
+        x = init_weights.uniform(f"fix.unet.{case}.x", (B, cfg["in_channels"], T), 11, -2.0, 2.0)
+        if tvals is None:
+            t = torch.tensor([999, 0], dtype=torch.long)
+        else:
+            t = torch.tensor(tvals, dtype=torch.float32)
+        caught = {}
+        hooks = []
+        if case == "a":
+            for name in taps:
+                def mk(nm):
+                    def hook(_m, _i, o):
+                        o0 = o[0] if isinstance(o, tuple) else o
+                        caught[nm] = o0.detach().numpy().copy()
+                    return hook
+                hooks.append(mods[name].register_forward_hook(mk(name)))
+        y = unet(tt(x), t).sample.numpy()
+        for h in hooks:
+            h.remove()
+        out[f"{case}_x"] = x
+        out[f"{case}_t"] = t.numpy()
+        out[f"{case}_y"] = y
+        for k, v in caught.items():
+            out[f"{case}_tap_{k}"] = v
+        print("unet case", case, y.shape, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(HERE, "unet_fwd.npz"), **out)
+
+    # ---------------- solver algebra with an analytic eps model ---------------------
+    B, M, T = 2, 80, 8
+    xT = init_weights.uniform("fix.toy.xT", (B, 1, M, T), 12, -1.7, 1.7)
+    cond = init_weights.uniform("fix.toy.cond", (B, 256, T), 12, -1.0, 1.0)
+    betas = gd.betas
+
+    def toy(xin, t_in):
+        # xin [B, 336, T] (x ++ cond), t_in [B]
+        xx = xin[:, :M]
+        return 0.5 * torch.sin(xx + t_in[:, None, None] * 0.001) + 0.1 * xin[:, M:2 * M]
+
+    def wrapped(x, t, cond):
+        return toy(torch.cat([x[:, 0], cond], dim=-2), t)[:, None]
+
+    toyres = {"xT": xT, "cond": cond}
+    for S in (50, 20, 6, 2):
+        ns = dpm_solver_pytorch.NoiseScheduleVP(schedule="discrete", betas=betas)
+        fn = dpm_solver_pytorch.model_wrapper(wrapped, ns, model_type="noise", model_kwargs={"cond": tt(cond)})
+        s = dpm_solver_pytorch.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+        toyres[f"dpm_{S}"] = s.sample(tt(xT), steps=S, order=2, skip_type="time_uniform", method="multistep").numpy()
+        ns = uni_pc.NoiseScheduleVP(schedule="discrete", betas=betas)
+        fn = uni_pc.model_wrapper(wrapped, ns, model_type="noise", model_kwargs={"cond": tt(cond)})
+        s = uni_pc.UniPC(fn, ns, variant="bh2")
+        toyres[f"unipc_{S}"] = s.sample(tt(xT), steps=S, order=2, skip_type="time_uniform", method="multistep").numpy()
+    # schedule scalars the solvers derive (for the coefficient-table tests)
+    ns = dpm_solver_pytorch.NoiseScheduleVP(schedule="discrete", betas=betas)
+    ts = torch.linspace(1.0, 1.0 / 1000, 51)
+    toyres["grid50_t"] = ts.numpy()
+    toyres["grid50_logalpha"] = torch.stack([ns.marginal_log_mean_coeff(t[None]) for t in ts]).reshape(-1).numpy()
+    toyres["grid50_sigma"] = torch.stack([ns.marginal_std(t[None]) for t in ts]).reshape(-1).numpy()
+    toyres["grid50_lambda"] = torch.stack([ns.marginal_lambda(t[None]) for t in ts]).reshape(-1).numpy()
+    toyres["log_alpha_array"] = ns.log_alpha_array.numpy()
+    np.savez_compressed(os.path.join(HERE, "solver_toy.npz"), **toyres)
+    print("toy solver done")
+
+    # ---------------- full sampler through GaussianDiffusion.forward ----------------
+    B, T = 2, 32
+    condBT = init_weights.uniform("fix.samp.cond", (B, T, 256), 13, -1.0, 1.0)
+    res = {"cond": condBT}
+    real_randn = torch.randn
+
+    def run(method, speedup, k_step=None, B_=B, seed=2):
+        drawn = []
+
+        def rec_randn(*a, **k):
+            k.pop("device", None)
+            v = real_randn(*a, **k)
+            drawn.append(v.numpy().copy())
+            return v
+        torch.manual_seed(seed)
+        torch.randn = rec_randn
+        try:
+            gd.k_step = 1000 if k_step is None else k_step
+            y = gd(tt(condBT[:B_]), infer=True, infer_speedup=speedup, method=method).numpy()
+        finally:
+            torch.randn = real_randn
+            gd.k_step = 1000
+        return y, np.stack([d.reshape(drawn[0].shape) for d in drawn])
+
+    for name, (method, speedup, k_step, b_) in {
+        "dpm50": ("dpm-solver", 20, None, B),
+        "unipc20": ("unipc", 50, None, B),
+        "ddim10": ("ddim", 100, None, B),
+        "pndm10": ("pndm", 100, None, 1),
+        "ddpm12": (None, 1, 12, B),
+    }.items():
+        y, noise = run(method, speedup, k_step, b_)
+        res[name + "_y"] = y
+        res[name + "_noise"] = noise
+        print("sampler", name, y.shape, noise.shape, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **res)
+
+    # ---------------- vocoder -------------------------------------------------------
+    h = arch.SYNTHETIC_VOCODER_H
+    g = Generator(h)
+    gsh = arch.generator_param_shapes(h)
+    json.dump({k: list(v.shape) for k, v in g.state_dict().items()},
+              open(os.path.join(HERE, "manifest_generator.json"), "w"), indent=0)
+    g.load_state_dict({k: tt(v) for k, v in init_weights.init_state(gsh, SEED_W).items()}, strict=True)
+    g.eval()
+    g.remove_weight_norm()
+    z = init_weights.uniform("fix.voc.z", (2, 12, 80), 14, -1.5, 1.5)     # mel layout [B,T,C]
+    wav = g(tt(z).transpose(-1, -2)).numpy()
+    print("vocoder", wav.shape, float(np.abs(wav).max()))
+    np.savez_compressed(os.path.join(HERE, "vocoder.npz"), z=z, wav=wav)
+
+
+if __name__ == "__main__":
+    main()
