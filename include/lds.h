@@ -1,0 +1,161 @@
+/*
+ * liblds.so -- C ABI of the MI355X-native latent-diffusion speech sampler.
+ *
+ * The reference (bfloat16/latent-diffusion-speech) is pure Python on PyTorch and has no
+ * FFI layer of its own; its drop-in boundary is the module API
+ *   diffusion.unit2mel.Unit2Mel / load_model_vocoder   (reference diffusion/unit2mel.py:18-88)
+ *   diffusion.diffusion.GaussianDiffusion.forward      (reference diffusion/diffusion.py:189-343)
+ *   diffusion.vocoder.Vocoder.infer                    (reference diffusion/vocoder.py:32-33)
+ * which the modules under latent-diffusion-speech_amd/diffusion/ re-expose unchanged.  Those modules keep
+ * tensors, streams and checkpoints in PyTorch and call the entry points below through ctypes
+ * (latent-diffusion-speech_amd/lds/native.py); INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is device memory owned by the caller (a torch tensor);
+ *     "host" pointers are read during the call only.
+ *   - activations are fp32, channel-major [B, C, T] with the frame axis contiguous.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it and
+ *     never synchronises.  Handles are immutable after create, so calls on different
+ *     streams are safe as long as each has its own workspace.
+ *   - return value 0 = ok, negative LDS_E* on error; lds_last_error() gives the message
+ *     (thread-local).  Nothing throws or aborts.
+ */
+#ifndef LDS_H
+#define LDS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDS_OK 0
+#define LDS_EINVAL (-1)    /* bad argument / unsupported shape */
+#define LDS_ENOMEM (-2)    /* workspace too small or device allocation failed */
+#define LDS_EHIP (-3)      /* a HIP runtime call failed */
+#define LDS_EMISSING (-4)  /* a required weight tensor was not supplied */
+
+typedef struct lds_unet lds_unet;
+typedef struct lds_embed lds_embed;
+typedef struct lds_vocoder lds_vocoder;
+
+const char* lds_last_error(void);
+int lds_version(void);
+
+/* ---- denoiser: UNet1DConditionModel (reference diffusion/unet1d/unet_1d_condition.py:61-1036,
+ *      configured as in reference diffusion/unit2mel.py:62-71) ------------------------------ */
+typedef struct {
+    int out_dims;              /* mel channels M (x / eps channels)                       */
+    int n_hidden;              /* condition channels H; UNet in_channels = M + H          */
+    int n_layers;              /* layers_per_block                                        */
+    int n_heads;               /* attention heads (reference attention_head_dim)          */
+    int norm_groups;           /* GroupNorm groups (8)                                    */
+    int n_blocks;              /* len(block_out_channels), <= 8                           */
+    int block_out_channels[8];
+} lds_unet_cfg;
+
+/* names[i] are the reference's state_dict keys of UNet1DConditionModel (e.g.
+ * "down_blocks.0.resnets.0.conv1.weight"), host_ptrs[i] fp32 host arrays in the reference's
+ * own layouts, numel[i] their element counts.  Weights are re-laid-out and uploaded once. */
+int lds_unet_create(const lds_unet_cfg* cfg, int n_tensors, const char* const* names,
+                    const float* const* host_ptrs, const int64_t* numel, lds_unet** out);
+void lds_unet_destroy(lds_unet* u);
+int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t* out);
+
+/* One denoiser evaluation = `self.denoise_fn(cat([x, cond], dim=-2), t).sample`
+ * (reference diffusion/diffusion.py:105-106,223-226).
+ * x dev [B,M,T], cond dev [B,H,T], t dev [B] (fp32, may be fractional), eps dev [B,M,T]. */
+int lds_unet_forward(lds_unet* u, const float* x, const float* cond, const float* t, float* eps,
+                     void* ws, size_t ws_bytes, int B, int T, void* stream);
+
+/* ---- sampler: GaussianDiffusion.forward(infer=True) loops (reference diffusion/diffusion.py:
+ *      214-341; DPM-Solver++ dpm_solver_pytorch.py:1171-1213; UniPC uni_pc.py:590-658) -------- */
+#define LDS_METHOD_DPM_SOLVER_PP 1
+#define LDS_METHOD_UNIPC 2
+#define LDS_METHOD_DDPM 3
+#define LDS_METHOD_DDIM 4
+#define LDS_METHOD_PLMS 5
+#define LDS_TABLE_STRIDE 16
+
+/* `table` (host, n_rows x LDS_TABLE_STRIDE floats) holds the per-step scalar coefficients,
+ * computed by the caller from the noise schedule in fp32 (layout per method: see
+ * latent-diffusion-speech_amd/diffusion/diffusion.py and csrc/sampler.hip).
+ * x dev [B,M,T] is x_T on entry and the sample on return; cond dev [B,H,T];
+ * noise dev [n_rows,B,M,T] for DDPM (one draw per step), else NULL. */
+int lds_sampler_run(lds_unet* u, int method, int n_rows, const float* table, const float* cond,
+                    float* x, const float* noise, void* ws, size_t ws_bytes, int B, int T,
+                    void* stream);
+int lds_sampler_workspace_bytes(const lds_unet* u, int B, int T, size_t* out);
+
+/* ---- front end: Unit2Mel.forward's condition (reference diffusion/unit2mel.py:79-82) ---------
+ * cond[b,:,t] = unit_embed(units[b,t,:]) + spk_embed[spk_id[b]-1]                               */
+int lds_embed_create(int input_channel, int n_hidden, int n_spk, const float* unit_w,
+                     const float* unit_b, const float* spk_w, lds_embed** out);
+void lds_embed_destroy(lds_embed* e);
+int lds_embed_workspace_bytes(const lds_embed* e, int B, int T, size_t* out);
+/* units dev [B,T,input_channel], spk_id dev [B] int64 (1-based, may be NULL when n_spk<=1),
+ * cond dev [B,n_hidden,T]. */
+int lds_embed_forward(lds_embed* e, const float* units, const int64_t* spk_id, float* cond,
+                      void* ws, size_t ws_bytes, int B, int T, void* stream);
+
+/* out[b,c,r] = in[b,r,c] / div  (the [B,T,M] <-> [B,M,T] layout changes at the module
+ * boundary: reference diffusion/diffusion.py:190,342-343, hifi_vaegan.py:54). */
+int lds_transpose(const float* in, float* out, int B, int R, int C, float div, void* stream);
+/* out = c0*a + c1*b over n elements (q_sample of shallow diffusion, reference diffusion.py:169-171) */
+int lds_axpby(float* out, const float* a, const float* b, float c0, float c1, int64_t n, void* stream);
+
+/* ---- vocoder: HiFi-VAEGAN Generator (reference encoder/hifi_vaegan/modules/models.py:224-272,
+ *      hifi_vaegan.py:52-65) ------------------------------------------------------------------- */
+typedef struct {
+    int inter_channels;             /* latent / mel channels                                */
+    int upsample_initial_channel;
+    int n_ups;                      /* <= 8 */
+    int upsample_rates[8];
+    int upsample_kernel_sizes[8];
+    int resblock;                   /* 1 or 2 */
+    int n_kernels;                  /* <= 4 */
+    int resblock_kernel_sizes[4];
+    int n_dil;                      /* dilations per resblock, <= 4 */
+    int resblock_dilation_sizes[4][4];
+} lds_vocoder_cfg;
+
+/* names: the reference Generator's state_dict keys; weight-norm pairs (`*.weight_g`,
+ * `*.weight_v`) are folded here like remove_weight_norm() (reference hifi_vaegan.py:61);
+ * already-folded `*.weight` tensors are accepted too. */
+int lds_vocoder_create(const lds_vocoder_cfg* cfg, int n_tensors, const char* const* names,
+                       const float* const* host_ptrs, const int64_t* numel, lds_vocoder** out);
+void lds_vocoder_destroy(lds_vocoder* v);
+int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out);
+/* z dev [B,C,T] -> wav dev [B,1,T*prod(upsample_rates)] */
+int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes,
+                        int B, int T, void* stream);
+
+/* ---- single-op entry points (used by the parity tests to check each kernel alone) ----------- */
+typedef struct {
+    const float* x1; const float* x2;   /* dev inputs [B,C1,Tsrc], [B,C2,Tsrc] (x2 may be NULL)  */
+    int C1, C2, Tsrc;
+    const float* w;                     /* host, reference layout [Co, C1+C2, K]                  */
+    const float* bias;                  /* host [Co] or NULL                                      */
+    int Co, K, stride, pad, dil, upsample2x;
+    int norm_mode;                      /* 0 none, 1 GroupNorm, 2 LayerNorm(over channels)        */
+    int groups; float eps;
+    const float* gamma; const float* beta;        /* host [C1+C2]                                 */
+    const float* scale_shift;           /* dev [B, 2*(C1+C2)] or NULL (resnet scale/shift)        */
+    int act_in;                         /* 0 none, 1 SiLU, 2 LeakyReLU(slope)                     */
+    float slope;
+    const float* res;                   /* dev [B,Co,To] or NULL                                  */
+    int epilogue;                       /* 0 none, 1 GEGLU (Co = 2*out channels), 2 tanh          */
+    int tile;                           /* 0 auto, else BM*1000+BN                                */
+} lds_conv_test;
+int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream);
+/* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
+int lds_test_attention(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
+int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
+                            float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
+                            float in_slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDS_H */

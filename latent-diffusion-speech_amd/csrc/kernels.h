@@ -1,0 +1,105 @@
+// Internal kernel interfaces of liblds (gfx950 only).  Activations: fp32 [B,C,T], T contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace lds {
+
+// ---------------------------------------------------------------------------------------------
+// conv_gemm: out[b,co,t] = epi( bias[co] + sum_{tap,ci} Wp[tap][ci][co] * f(X[b,ci, t*stride + tap*dil - pad]) )
+// f = optional normalise-on-load (GroupNorm via per-(b,ci) coefficients, or LayerNorm over channels
+// via per-(b,t) statistics) followed by an optional activation; out-of-range taps read exact zeros.
+// The MFMA is v_mfma_f32_32x32x2_f32 (exact fp32); A = packed weights (M = co), B = activations (N = t).
+// ---------------------------------------------------------------------------------------------
+enum { NORM_NONE = 0, NORM_ROWCOEF = 1, NORM_COLSTAT = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
+enum { EPI_NONE = 0, EPI_GEGLU = 1, EPI_TANH = 2 };
+
+struct ConvArgs {
+    // input: virtual channel-concat of two sources (x2 for ci >= C1)
+    const float* x1; const float* x2;
+    int C1, C2;
+    int Tsrc;            // stored row length of the sources
+    int Tin;             // logical input length (2*Tsrc when ups)
+    long long xb1, xb2;  // batch strides (elements)
+    // packed weights [KT][Ci][Mp]
+    const float* w;
+    int Mp, Co, Ci, KT, stride, dil, pad, ups;
+    // normalise-on-load
+    int norm_mode;
+    const float4* coef;      // NORM_ROWCOEF: [B][Ci] {mu, a, b, -}: v = (x-mu)*a + b
+    const float* cmean; const float* crstd;   // NORM_COLSTAT: [B][Tsrc]
+    const float* gamma; const float* beta;    // NORM_COLSTAT: [Ci]
+    int act_in; float slope;
+    // epilogue
+    const float* bias;       // [Co] (for GEGLU: packed order, Mp entries) or null
+    const float* bias_bc;    // [B][Co] extra per-(batch,channel) bias or null
+    const float* res;        // [B][Cout][To] residual or null
+    int epi;
+    int accum;               // 1: out = (out + y) / out_div  (MRF running sum), 0: out = y / out_div
+    float out_div;           // 1.0 normally
+    float* out;
+    int Cout;                // channels of `out` (Co, or Co/2 for GEGLU, or Co/phases for transposed conv)
+    int To;                  // columns computed (N)
+    // transposed-conv scatter: row m = co*phases + phi -> out[b][co][n*phases + phi - tpad] (phases=1: plain)
+    int phases, tpad, Tout;  // Tout = row length of out
+    int B;
+};
+
+// tile: 0 = auto, else BM*1000+BN in {128128, 64064, 128064, 64128, 32128}
+hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s);
+const char* conv_gemm_last_config();
+
+// Weight packers (host side): reference layout -> [KT][Ci][Mp]
+size_t packed_conv_elems(int Co, int Ci, int K, int* Mp_out);
+
+// ---------------------------------------------------------------------------------------------
+// Normalisation statistics
+// ---------------------------------------------------------------------------------------------
+// GroupNorm over the virtual concat [x1;x2] -> coef[b][ci] = {mean_g, rstd_g*gamma*(1+scale), beta*(1+scale)+shift, 0}
+hipError_t launch_gn_coef(const float* x1, const float* x2, int C1, int C2, int T, long long xb1, long long xb2,
+                          int groups, float eps, const float* gamma, const float* beta,
+                          const float* scale_shift /*[B][ss_stride] scale at +ss_off, shift at +ss_off+C or null*/,
+                          int ss_stride, int ss_off, float4* coef, int B, hipStream_t s);
+// LayerNorm statistics over channels: mean[b][t], rstd[b][t]
+hipError_t launch_ln_stats(const float* x, int C, int T, float eps, float* mean, float* rstd, int B, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention: qkv [B][3C][T] (q rows 0..C-1, k rows C..2C-1, v rows 2C..3C-1) -> out [B][C][T]
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_attention(const float* qkv, float* out, int B, int C, int T, int heads, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Small dense layers with N = batch columns (time embedding path)
+// out[b][m] = sum_k W[m][k] * g(in[b][k]) + bias[m];  g = identity | SiLU | sinusoid(t[b])
+// ---------------------------------------------------------------------------------------------
+enum { IN_PLAIN = 0, IN_SILU = 1, IN_SINUSOID = 2 };
+hipError_t launch_small_linear(const float* W, const float* bias, const float* in, int in_stride, int in_mode,
+                               const float* freqs, float* out, int out_stride, int M, int K, int B, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Elementwise sampler updates over n = B*M*T elements
+// ---------------------------------------------------------------------------------------------
+enum {
+    EW_X0 = 1,        // out = (a - c0*b) / c1                         (x0 = (x - sigma*eps)/alpha)
+    EW_AXPBY = 2,     // out = c0*a - c1*b                             (DPM first-order / UniPC x_t_)
+    EW_DPM2 = 3,      // out = c0*a - c1*b - c2*(c3*(b - c))           (DPM-Solver++ 2M)
+    EW_UNIPC_PRED = 4,// out = a - c0*(c1*((c - b)/c2))                (a = x_t_, b = m0, c = m_prev1)
+    EW_UNIPC_CORR = 5,// out = a - c0*(c1*((d - b)/c2) + c3*(c - b))   (a = x_t_, b = m0, c = m_t, d = m_prev1)
+    EW_UNIPC_CORR1 = 6,// out = a - c0*(c3*(c - b))                    (order-1 corrector)
+    EW_DDPM = 7,      // x0 = clamp(c0*a - c1*b, -1, 1); out = c2*x0 + c3*a + c4*c   (a = x, b = eps, c = noise)
+    EW_DDIM = 8,      // out = c0*(a/c1 + c2*b)
+    EW_PLMS_PRED = 9, // out = a + c0*(c1*a - c2*b)
+    EW_LIN4 = 10,     // out = (c0*a + c1*b + c2*c + c3*d) / c4
+    EW_COPY = 11
+};
+hipError_t launch_ew(int op, float* out, const float* a, const float* b, const float* c, const float* d,
+                     float c0, float c1, float c2, float c3, float c4, long long n, hipStream_t s);
+hipError_t launch_fill(float* p, float v, long long n, hipStream_t s);
+hipError_t launch_transpose(const float* in, float* out, int B, int R, int C, float scale, hipStream_t s);
+hipError_t launch_gather_rows(const float* table, const int64_t* idx, int idx_off, float* out, int B, int C,
+                              int nrows, hipStream_t s);
+hipError_t launch_resample_nearest(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
+
+}  // namespace lds

@@ -1,0 +1,1087 @@
+// Host side of liblds: weight packing, the UNet1D forward plan, the sampler loops, the front end
+// and the vocoder, exported through the C ABI in include/lds.h.  Everything here only enqueues
+// kernels on the caller's stream; no allocation or synchronisation happens after *_create.
+#include "../../include/lds.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace lds;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* lds_last_error(void) { return g_err; }
+extern "C" int lds_version(void) { return 1; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(LDS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LDS_TRY(expr)                    \
+    do {                                 \
+        int r_ = (expr);                 \
+        if (r_ != LDS_OK) return r_;     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device allocations owned by a handle
+// ------------------------------------------------------------------------------------------------
+struct Owner {
+    std::vector<void*> ptrs;
+    ~Owner() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    float* upload(const std::vector<float>& h) {
+        void* d = nullptr;
+        if (hipMalloc(&d, h.size() * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return nullptr;
+        }
+        ptrs.push_back(d);
+        return (float*)d;
+    }
+};
+
+struct Tensors {
+    std::map<std::string, std::pair<const float*, int64_t>> m;
+    std::string missing;
+    const float* get(const std::string& k, int64_t numel) {
+        auto it = m.find(k);
+        if (it == m.end() || it->second.second != numel) {
+            if (missing.empty()) missing = k + (it == m.end() ? " (absent)" : " (wrong size)");
+            return nullptr;
+        }
+        return it->second.first;
+    }
+    bool has(const std::string& k) const { return m.count(k) != 0; }
+};
+
+// packed conv / linear weights: [KT][Ci][Mp] + bias[Mp]
+struct ConvW {
+    float* w = nullptr;
+    float* bias = nullptr;
+    int Co = 0, Ci = 0, K = 1, Mp = 0;
+};
+
+static int round_mp(int Co) { return Co <= 32 ? 32 : (Co + 63) / 64 * 64; }
+
+// reference layout w[Co][Ci][K] (or [Co][Ci] for Linear) -> packed
+static bool pack_conv(Owner& o, const float* w, const float* b, int Co, int Ci, int K, ConvW& out) {
+    const int Mp = round_mp(Co);
+    std::vector<float> p((size_t)K * Ci * Mp, 0.f), pb(Mp, 0.f);
+    for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci)
+            for (int k = 0; k < K; ++k) p[((size_t)k * Ci + ci) * Mp + co] = w[((size_t)co * Ci + ci) * K + k];
+    if (b)
+        for (int co = 0; co < Co; ++co) pb[co] = b[co];
+    out.w = o.upload(p);
+    out.bias = b ? o.upload(pb) : nullptr;
+    out.Co = Co; out.Ci = Ci; out.K = K; out.Mp = Mp;
+    return out.w && (!b || out.bias);
+}
+
+// GEGLU projection (reference attention.py:280-301): rows [0,4C) are the value half, [4C,8C) the gate.
+// Interleave them in 32-row groups so one wave's two MFMA row tiles hold value and gate of the same channels.
+static bool pack_geglu(Owner& o, const float* w, const float* b, int C8, int Ci, ConvW& out) {
+    const int half = C8 / 2;
+    std::vector<float> p((size_t)Ci * C8, 0.f), pb(C8, 0.f);
+    for (int m = 0; m < C8; ++m) {
+        const int q = m / 64, s = (m % 64) / 32, r = m % 32;
+        const int src = (s == 0 ? 0 : half) + 32 * q + r;
+        for (int ci = 0; ci < Ci; ++ci) p[(size_t)ci * C8 + m] = w[(size_t)src * Ci + ci];
+        pb[m] = b[src];
+    }
+    out.w = o.upload(p);
+    out.bias = o.upload(pb);
+    out.Co = C8; out.Ci = Ci; out.K = 1; out.Mp = C8;
+    return out.w && out.bias;
+}
+
+// ConvTranspose1d (reference models.py:233-236) as `stride` interleaved phase filters of K/stride taps:
+// packed[tap][ci][co*stride + phi] = w[ci][co][phi + stride*(KT-1-tap)]
+static bool pack_convT(Owner& o, const float* w, const float* b, int Ci, int Co, int K, int stride, ConvW& out) {
+    const int KT = K / stride, M = Co * stride, Mp = round_mp(M);
+    std::vector<float> p((size_t)KT * Ci * Mp, 0.f), pb(Mp, 0.f);
+    for (int tap = 0; tap < KT; ++tap)
+        for (int ci = 0; ci < Ci; ++ci)
+            for (int co = 0; co < Co; ++co)
+                for (int phi = 0; phi < stride; ++phi)
+                    p[((size_t)tap * Ci + ci) * Mp + co * stride + phi] = w[((size_t)ci * Co + co) * K + phi + stride * (KT - 1 - tap)];
+    for (int co = 0; co < Co; ++co)
+        for (int phi = 0; phi < stride; ++phi) pb[co * stride + phi] = b ? b[co] : 0.f;
+    out.w = o.upload(p);
+    out.bias = o.upload(pb);
+    out.Co = M; out.Ci = Ci; out.K = KT; out.Mp = Mp;
+    return out.w && out.bias;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace bump allocator (caller-owned memory)
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    char* base; size_t cap; size_t used = 0; bool ok = true;
+    Arena(void* p, size_t n) : base((char*)p), cap(n) {}
+    float* f(size_t n_floats) {
+        size_t bytes = (n_floats * sizeof(float) + 255) & ~(size_t)255;
+        if (base && used + bytes > cap) ok = false;
+        char* p = base ? base + used : nullptr;
+        used += bytes;
+        return (float*)p;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// conv helper
+// ------------------------------------------------------------------------------------------------
+struct Src {
+    const float* x1; int C1; const float* x2; int C2; int Tsrc;
+};
+struct ConvOpt {
+    int stride = 1, pad = 0, dil = 1, ups = 0;
+    int norm_mode = NORM_NONE; const float4* coef = nullptr;
+    const float* cmean = nullptr; const float* crstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    int act_in = ACT_NONE; float slope = 0.f;
+    const float* bias_bc = nullptr; const float* res = nullptr;
+    int epi = EPI_NONE; int accum = 0; float out_div = 1.f;
+    int phases = 1, tpad = 0; int To = -1; int Tout = -1; int tile = 0;
+    int Cout = -1;
+};
+
+static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, int B, hipStream_t st) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = s.x1; a.x2 = s.x2 ? s.x2 : s.x1; a.C1 = s.C1; a.C2 = s.C2; a.Tsrc = s.Tsrc;
+    a.Tin = o.ups ? 2 * s.Tsrc : s.Tsrc;
+    a.xb1 = (long long)s.C1 * s.Tsrc; a.xb2 = (long long)s.C2 * s.Tsrc;
+    a.w = W.w; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
+    a.stride = o.stride; a.dil = o.dil; a.pad = o.pad; a.ups = o.ups;
+    a.norm_mode = o.norm_mode; a.coef = o.coef; a.cmean = o.cmean; a.crstd = o.crstd; a.gamma = o.gamma; a.beta = o.beta;
+    a.act_in = o.act_in; a.slope = o.slope;
+    a.bias = W.bias; a.bias_bc = o.bias_bc; a.res = o.res; a.epi = o.epi; a.accum = o.accum; a.out_div = o.out_div;
+    a.out = out;
+    if (s.C1 + s.C2 != W.Ci) return fail(LDS_EINVAL, "conv: input channels %d+%d != %d", s.C1, s.C2, W.Ci);
+    const int To_nat = (a.Tin + 2 * o.pad - o.dil * (W.K - 1) - 1) / o.stride + 1;
+    a.To = o.To > 0 ? o.To : To_nat;
+    a.Tout = o.Tout > 0 ? o.Tout : a.To;
+    a.phases = o.phases; a.tpad = o.tpad;
+    a.Cout = o.Cout > 0 ? o.Cout : (o.epi == EPI_GEGLU ? W.Co / 2 : W.Co / o.phases);
+    a.B = B;
+    hipError_t e = launch_conv_gemm(a, o.tile, st);
+    if (e != hipSuccess)
+        return fail(LDS_EHIP, "conv_gemm launch failed (%s): Co %d Ci %d K %d stride %d dil %d ups %d To %d", hipGetErrorString(e), W.Co,
+                    W.Ci, W.K, o.stride, o.dil, o.ups, a.To);
+    return LDS_OK;
+}
+
+// ================================================================================================
+// UNet
+// ================================================================================================
+struct ResnetW {
+    int cin = 0, cout = 0;
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    ConvW conv1, conv2, sc;
+    bool has_sc = false;
+    int temb_off = 0;
+};
+struct TfmW {
+    int C = 0;
+    float *gn_g = nullptr, *gn_b = nullptr;
+    float *ln_g[3] = {nullptr, nullptr, nullptr}, *ln_b[3] = {nullptr, nullptr, nullptr};
+    ConvW proj_in, proj_out, qkv[2], o[2], ff1, ff2;
+};
+struct DownBlk { std::vector<ResnetW> res; std::vector<TfmW> att; bool has_down = false; ConvW down; int ch = 0; };
+struct UpBlk { std::vector<ResnetW> res; std::vector<TfmW> att; std::vector<int> skip_ch; bool has_up = false; ConvW up; int ch = 0; };
+
+struct lds_unet {
+    lds_unet_cfg cfg;
+    Owner own;
+    int M = 0, H = 0, G = 8, heads = 8, temb = 0, tproj_dim = 0;
+    ConvW conv_in, conv_out;
+    float *gno_g = nullptr, *gno_b = nullptr;
+    float* freqs = nullptr;
+    float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+    float *tp_w = nullptr, *tp_b = nullptr;
+    int tp_M = 0;
+    std::vector<DownBlk> down;
+    ResnetW mid_r0, mid_r1;
+    TfmW mid_t;
+    std::vector<UpBlk> up;
+    int max_ci = 0;
+};
+
+static float* up_vec(Owner& o, const float* p, int64_t n) {
+    if (!p) return nullptr;
+    return o.upload(std::vector<float>(p, p + n));
+}
+
+static bool load_resnet(lds_unet* u, Tensors& T, const std::string& p, int cin, int cout, std::vector<float>& tpw,
+                        std::vector<float>& tpb, ResnetW& r) {
+    Owner& o = u->own;
+    r.cin = cin; r.cout = cout;
+    r.g1 = up_vec(o, T.get(p + "norm1.weight", cin), cin);
+    r.b1 = up_vec(o, T.get(p + "norm1.bias", cin), cin);
+    r.g2 = up_vec(o, T.get(p + "norm2.weight", cout), cout);
+    r.b2 = up_vec(o, T.get(p + "norm2.bias", cout), cout);
+    const float* w1 = T.get(p + "conv1.weight", (int64_t)cout * cin * 3);
+    const float* c1b = T.get(p + "conv1.bias", cout);
+    const float* w2 = T.get(p + "conv2.weight", (int64_t)cout * cout * 3);
+    const float* c2b = T.get(p + "conv2.bias", cout);
+    const float* tw = T.get(p + "time_emb_proj.weight", (int64_t)2 * cout * u->temb);
+    const float* tb = T.get(p + "time_emb_proj.bias", 2 * cout);
+    if (!r.g1 || !r.b1 || !r.g2 || !r.b2 || !w1 || !c1b || !w2 || !c2b || !tw || !tb) return false;
+    if (!pack_conv(o, w1, c1b, cout, cin, 3, r.conv1)) return false;
+    if (!pack_conv(o, w2, c2b, cout, cout, 3, r.conv2)) return false;
+    r.has_sc = cin != cout;
+    if (r.has_sc) {
+        const float* ws = T.get(p + "conv_shortcut.weight", (int64_t)cout * cin);
+        const float* bs = T.get(p + "conv_shortcut.bias", cout);
+        if (!ws || !bs || !pack_conv(o, ws, bs, cout, cin, 1, r.sc)) return false;
+    }
+    r.temb_off = (int)tpb.size();
+    tpw.insert(tpw.end(), tw, tw + (size_t)2 * cout * u->temb);
+    tpb.insert(tpb.end(), tb, tb + 2 * cout);
+    if (cin > u->max_ci) u->max_ci = cin;
+    return true;
+}
+
+static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW& t) {
+    Owner& o = u->own;
+    t.C = C;
+    t.gn_g = up_vec(o, T.get(p + "norm.weight", C), C);
+    t.gn_b = up_vec(o, T.get(p + "norm.bias", C), C);
+    const float* piw = T.get(p + "proj_in.weight", (int64_t)C * C);
+    const float* pib = T.get(p + "proj_in.bias", C);
+    const float* pow_ = T.get(p + "proj_out.weight", (int64_t)C * C);
+    const float* pob = T.get(p + "proj_out.bias", C);
+    if (!t.gn_g || !t.gn_b || !piw || !pib || !pow_ || !pob) return false;
+    if (!pack_conv(o, piw, pib, C, C, 1, t.proj_in) || !pack_conv(o, pow_, pob, C, C, 1, t.proj_out)) return false;
+    const std::string b = p + "transformer_blocks.0.";
+    for (int i = 0; i < 3; ++i) {
+        const std::string n = b + "norm" + std::to_string(i + 1);
+        t.ln_g[i] = up_vec(o, T.get(n + ".weight", C), C);
+        t.ln_b[i] = up_vec(o, T.get(n + ".bias", C), C);
+        if (!t.ln_g[i] || !t.ln_b[i]) return false;
+    }
+    for (int i = 0; i < 2; ++i) {
+        const std::string a = b + "attn" + std::to_string(i + 1) + ".";
+        const float* q = T.get(a + "to_q.weight", (int64_t)C * C);
+        const float* k = T.get(a + "to_k.weight", (int64_t)C * C);
+        const float* v = T.get(a + "to_v.weight", (int64_t)C * C);
+        const float* ow = T.get(a + "to_out.0.weight", (int64_t)C * C);
+        const float* ob = T.get(a + "to_out.0.bias", C);
+        if (!q || !k || !v || !ow || !ob) return false;
+        std::vector<float> cat((size_t)3 * C * C);
+        memcpy(cat.data(), q, sizeof(float) * C * C);
+        memcpy(cat.data() + (size_t)C * C, k, sizeof(float) * C * C);
+        memcpy(cat.data() + (size_t)2 * C * C, v, sizeof(float) * C * C);
+        if (!pack_conv(o, cat.data(), nullptr, 3 * C, C, 1, t.qkv[i])) return false;
+        if (!pack_conv(o, ow, ob, C, C, 1, t.o[i])) return false;
+    }
+    const float* f1 = T.get(b + "ff.net.0.proj.weight", (int64_t)8 * C * C);
+    const float* f1b = T.get(b + "ff.net.0.proj.bias", 8 * C);
+    const float* f2 = T.get(b + "ff.net.2.weight", (int64_t)C * 4 * C);
+    const float* f2b = T.get(b + "ff.net.2.bias", C);
+    if (!f1 || !f1b || !f2 || !f2b) return false;
+    if (!pack_geglu(o, f1, f1b, 8 * C, C, t.ff1)) return false;
+    if (!pack_conv(o, f2, f2b, C, 4 * C, 1, t.ff2)) return false;
+    return true;
+}
+
+extern "C" int lds_unet_create(const lds_unet_cfg* cfg, int n, const char* const* names, const float* const* ptrs,
+                               const int64_t* numel, lds_unet** out) {
+    if (!cfg || !names || !ptrs || !numel || !out) return fail(LDS_EINVAL, "null argument");
+    if (cfg->n_blocks < 2 || cfg->n_blocks > 8) return fail(LDS_EINVAL, "n_blocks %d unsupported", cfg->n_blocks);
+    Tensors T;
+    for (int i = 0; i < n; ++i) T.m[names[i]] = {ptrs[i], numel[i]};
+    lds_unet* u = new lds_unet();
+    u->cfg = *cfg;
+    u->M = cfg->out_dims; u->H = cfg->n_hidden; u->G = cfg->norm_groups; u->heads = cfg->n_heads;
+    const int* boc = cfg->block_out_channels;
+    const int nb = cfg->n_blocks, L = cfg->n_layers;
+    u->tproj_dim = boc[0];
+    u->temb = boc[0] * 4;
+    for (int i = 0; i < nb; ++i) {
+        const int hd = boc[i] / cfg->n_heads;
+        if (boc[i] % 64 != 0 || boc[i] % cfg->norm_groups != 0 || (hd != 32 && hd != 48 && hd != 64)) {
+            delete u;
+            return fail(LDS_EINVAL, "block_out_channels[%d]=%d unsupported (need multiple of 64, head dim 32/48/64)", i, boc[i]);
+        }
+    }
+    if ((u->M % 16) || (u->H % 16)) { delete u; return fail(LDS_EINVAL, "out_dims and n_hidden must be multiples of 16"); }
+    Owner& o = u->own;
+    bool ok = true;
+    std::vector<float> tpw, tpb;
+    const int cin0 = u->M + u->H;
+    {
+        const float* w = T.get("conv_in.weight", (int64_t)boc[0] * cin0 * 3);
+        const float* b = T.get("conv_in.bias", boc[0]);
+        ok = ok && w && b && pack_conv(o, w, b, boc[0], cin0, 3, u->conv_in);
+        u->t_w1 = up_vec(o, T.get("time_embedding.linear_1.weight", (int64_t)u->temb * u->tproj_dim), (int64_t)u->temb * u->tproj_dim);
+        u->t_b1 = up_vec(o, T.get("time_embedding.linear_1.bias", u->temb), u->temb);
+        u->t_w2 = up_vec(o, T.get("time_embedding.linear_2.weight", (int64_t)u->temb * u->temb), (int64_t)u->temb * u->temb);
+        u->t_b2 = up_vec(o, T.get("time_embedding.linear_2.bias", u->temb), u->temb);
+        ok = ok && u->t_w1 && u->t_b1 && u->t_w2 && u->t_b2;
+        // Timesteps(flip_sin_to_cos=True, freq_shift=0): f_i = exp(-ln(1e4) * i / half), fp32 like the reference
+        const int half = u->tproj_dim / 2;
+        std::vector<float> fr(half);
+        for (int i = 0; i < half; ++i) fr[i] = expf(((float)(-log(10000.0)) * (float)i) / (float)half);
+        u->freqs = o.upload(fr);
+    }
+    // down blocks
+    std::vector<int> skip_ch{boc[0]};
+    int cprev = boc[0];
+    for (int i = 0; i < nb && ok; ++i) {
+        DownBlk d;
+        d.ch = boc[i];
+        const bool last = i == nb - 1;
+        const std::string p = "down_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < L && ok; ++j) {
+            ResnetW r;
+            ok = load_resnet(u, T, p + "resnets." + std::to_string(j) + ".", j == 0 ? cprev : boc[i], boc[i], tpw, tpb, r);
+            d.res.push_back(r);
+            if (!last && ok) {
+                TfmW t;
+                ok = load_tfm(u, T, p + "attentions." + std::to_string(j) + ".", boc[i], t);
+                d.att.push_back(t);
+            }
+            skip_ch.push_back(boc[i]);
+        }
+        if (!last && ok) {
+            d.has_down = true;
+            const float* w = T.get(p + "downsamplers.0.conv.weight", (int64_t)boc[i] * boc[i] * 3);
+            const float* b = T.get(p + "downsamplers.0.conv.bias", boc[i]);
+            ok = w && b && pack_conv(o, w, b, boc[i], boc[i], 3, d.down);
+            skip_ch.push_back(boc[i]);
+        }
+        cprev = boc[i];
+        u->down.push_back(d);
+    }
+    // mid
+    if (ok) {
+        const int c = boc[nb - 1];
+        ok = load_resnet(u, T, "mid_block.resnets.0.", c, c, tpw, tpb, u->mid_r0) &&
+             load_tfm(u, T, "mid_block.attentions.0.", c, u->mid_t) && load_resnet(u, T, "mid_block.resnets.1.", c, c, tpw, tpb, u->mid_r1);
+    }
+    // up blocks
+    int cout = boc[nb - 1];
+    for (int i = 0; i < nb && ok; ++i) {
+        UpBlk b;
+        const int prev = cout;
+        cout = boc[nb - 1 - i];
+        b.ch = cout;
+        const bool last = i == nb - 1;
+        const std::string p = "up_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < L + 1 && ok; ++j) {
+            const int sk = skip_ch.back();
+            skip_ch.pop_back();
+            const int hin = j == 0 ? prev : cout;
+            b.skip_ch.push_back(sk);
+            ResnetW r;
+            ok = load_resnet(u, T, p + "resnets." + std::to_string(j) + ".", hin + sk, cout, tpw, tpb, r);
+            b.res.push_back(r);
+            if (i != 0 && ok) {
+                TfmW t;
+                ok = load_tfm(u, T, p + "attentions." + std::to_string(j) + ".", cout, t);
+                b.att.push_back(t);
+            }
+        }
+        if (!last && ok) {
+            b.has_up = true;
+            const float* w = T.get(p + "upsamplers.0.conv.weight", (int64_t)cout * cout * 3);
+            const float* bb = T.get(p + "upsamplers.0.conv.bias", cout);
+            ok = w && bb && pack_conv(o, w, bb, cout, cout, 3, b.up);
+        }
+        u->up.push_back(b);
+    }
+    if (ok) {
+        u->gno_g = up_vec(o, T.get("conv_norm_out.weight", boc[0]), boc[0]);
+        u->gno_b = up_vec(o, T.get("conv_norm_out.bias", boc[0]), boc[0]);
+        const float* w = T.get("conv_out.weight", (int64_t)u->M * boc[0] * 3);
+        const float* b = T.get("conv_out.bias", u->M);
+        ok = u->gno_g && u->gno_b && w && b && pack_conv(o, w, b, u->M, boc[0], 3, u->conv_out);
+    }
+    if (ok) {
+        u->tp_M = (int)tpb.size();
+        u->tp_w = o.upload(tpw);
+        u->tp_b = o.upload(tpb);
+        ok = u->tp_w && u->tp_b;
+    }
+    if (cin0 > u->max_ci) u->max_ci = cin0;
+    if (!ok) {
+        std::string miss = T.missing;
+        delete u;
+        if (!miss.empty()) return fail(LDS_EMISSING, "weight tensor %s", miss.c_str());
+        return fail(LDS_ENOMEM, "device allocation / upload failed while packing weights");
+    }
+    *out = u;
+    return LDS_OK;
+}
+
+extern "C" void lds_unet_destroy(lds_unet* u) { delete u; }
+
+static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
+
+struct UnetWs {
+    float *e1, *emb, *tproj;
+    float4* coef;
+    float *lmean, *lrstd;
+    std::vector<float*> skips;
+    float *cur[2], *r, *h1, *sc, *ta, *tb, *qkv, *att, *ff, *upt;
+};
+
+static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
+    const int nb = u->cfg.n_blocks, L = u->cfg.n_layers;
+    const int* boc = u->cfg.block_out_channels;
+    w.e1 = A.f((size_t)B * u->temb);
+    w.emb = A.f((size_t)B * u->temb);
+    w.tproj = A.f((size_t)B * u->tp_M);
+    w.coef = (float4*)A.f((size_t)B * u->max_ci * 4);
+    w.lmean = A.f((size_t)B * T);
+    w.lrstd = A.f((size_t)B * T);
+    size_t maxct = 0, maxqkv = 0;
+    int Tl = T;
+    w.skips.clear();
+    w.skips.push_back(A.f((size_t)B * boc[0] * Tl));
+    for (int i = 0; i < nb; ++i) {
+        const size_t ct = (size_t)boc[i] * Tl;
+        if (ct > maxct) maxct = ct;
+        if (i > 0 && (size_t)boc[i - 1] * Tl > maxct) maxct = (size_t)boc[i - 1] * Tl;
+        if (i != nb - 1 && ct > maxqkv) maxqkv = ct;
+        for (int j = 0; j < L; ++j) w.skips.push_back(A.f((size_t)B * ct));
+        if (i != nb - 1) {
+            Tl = down_len(Tl);
+            w.skips.push_back(A.f((size_t)B * boc[i] * Tl));
+        }
+    }
+    // the up path revisits the same resolutions with channel counts <= max(boc) at each level
+    {
+        int Tu = T;
+        std::vector<int> Ts{T};
+        for (int i = 0; i < nb - 1; ++i) { Tu = down_len(Tu); Ts.push_back(Tu); }
+        for (int i = 0; i < nb; ++i) {
+            const int lvl = nb - 1 - i;              // resolution index of up block i
+            const size_t ct = (size_t)boc[nb - 1 - i] * Ts[lvl];
+            if (ct > maxct) maxct = ct;
+            if (i != 0 && ct > maxqkv) maxqkv = ct;
+            if (lvl > 0) { const size_t c2 = (size_t)boc[nb - 1 - i] * Ts[lvl - 1]; if (c2 > maxct) maxct = c2; }
+        }
+        if ((size_t)boc[nb - 1] * Ts[nb - 1] > maxqkv) maxqkv = (size_t)boc[nb - 1] * Ts[nb - 1];
+    }
+    w.cur[0] = A.f(B * maxct); w.cur[1] = A.f(B * maxct);
+    w.r = A.f(B * maxct); w.h1 = A.f(B * maxct); w.sc = A.f(B * maxct);
+    w.ta = A.f(B * maxct); w.tb = A.f(B * maxct); w.upt = A.f(B * maxct);
+    w.qkv = A.f(B * maxqkv * 3); w.att = A.f(B * maxqkv); w.ff = A.f(B * maxqkv * 4);
+}
+
+extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t* out) {
+    if (!u || !out || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    Arena A(nullptr, 0);
+    UnetWs w;
+    plan_ws(u, A, B, T, w);
+    *out = A.used;
+    return LDS_OK;
+}
+
+static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, const float* x1, int C1, const float* x2, int C2, int T,
+                      float* out, int B, hipStream_t st) {
+    // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut
+    HIP_TRY(launch_gn_coef(x1, x2 ? x2 : x1, C1, C2, T, (long long)C1 * T, (long long)C2 * T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0,
+                           w.coef, B, st));
+    Src s{x1, C1, x2, C2, T};
+    ConvOpt o1;
+    o1.pad = 1; o1.norm_mode = NORM_ROWCOEF; o1.coef = w.coef; o1.act_in = ACT_SILU;
+    LDS_TRY(run_conv(r.conv1, s, o1, w.h1, B, st));
+    const float* res = x1;
+    if (r.has_sc) {
+        ConvOpt os;
+        LDS_TRY(run_conv(r.sc, s, os, w.sc, B, st));
+        res = w.sc;
+    }
+    HIP_TRY(launch_gn_coef(w.h1, w.h1, r.cout, 0, T, (long long)r.cout * T, 0, u->G, 1e-5f, r.g2, r.b2, w.tproj, u->tp_M, r.temb_off,
+                           w.coef, B, st));
+    Src s2{w.h1, r.cout, nullptr, 0, T};
+    ConvOpt o2;
+    o2.pad = 1; o2.norm_mode = NORM_ROWCOEF; o2.coef = w.coef; o2.act_in = ACT_SILU; o2.res = res;
+    return run_conv(r.conv2, s2, o2, out, B, st);
+}
+
+static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st) {
+    // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major
+    const int C = t.C;
+    HIP_TRY(launch_gn_coef(x, x, C, 0, T, (long long)C * T, 0, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, w.coef, B, st));
+    Src sx{x, C, nullptr, 0, T};
+    ConvOpt op;
+    op.norm_mode = NORM_ROWCOEF; op.coef = w.coef;
+    LDS_TRY(run_conv(t.proj_in, sx, op, w.ta, B, st));
+    float* h = w.ta;
+    float* hn = w.tb;
+    for (int a = 0; a < 2; ++a) {
+        HIP_TRY(launch_ln_stats(h, C, T, 1e-5f, w.lmean, w.lrstd, B, st));
+        Src sh{h, C, nullptr, 0, T};
+        ConvOpt oq;
+        oq.norm_mode = NORM_COLSTAT; oq.cmean = w.lmean; oq.crstd = w.lrstd; oq.gamma = t.ln_g[a]; oq.beta = t.ln_b[a];
+        LDS_TRY(run_conv(t.qkv[a], sh, oq, w.qkv, B, st));
+        HIP_TRY(launch_attention(w.qkv, w.att, B, C, T, u->heads, st));
+        Src sa{w.att, C, nullptr, 0, T};
+        ConvOpt oo;
+        oo.res = h;
+        LDS_TRY(run_conv(t.o[a], sa, oo, hn, B, st));
+        float* tmp = h; h = hn; hn = tmp;
+    }
+    HIP_TRY(launch_ln_stats(h, C, T, 1e-5f, w.lmean, w.lrstd, B, st));
+    Src sh{h, C, nullptr, 0, T};
+    ConvOpt of;
+    of.norm_mode = NORM_COLSTAT; of.cmean = w.lmean; of.crstd = w.lrstd; of.gamma = t.ln_g[2]; of.beta = t.ln_b[2];
+    of.epi = EPI_GEGLU;
+    LDS_TRY(run_conv(t.ff1, sh, of, w.ff, B, st));
+    Src sf{w.ff, 4 * C, nullptr, 0, T};
+    ConvOpt o2;
+    o2.res = h;
+    LDS_TRY(run_conv(t.ff2, sf, o2, hn, B, st));
+    Src so{hn, C, nullptr, 0, T};
+    ConvOpt o3;
+    o3.res = x;
+    return run_conv(t.proj_out, so, o3, out, B, st);
+}
+
+static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
+                             int B, int T, hipStream_t st) {
+    Arena A(ws, ws_bytes);
+    UnetWs w;
+    plan_ws(u, A, B, T, w);
+    if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
+    const int nb = u->cfg.n_blocks;
+    // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch
+    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, u->temb, u->tproj_dim, B, st));
+    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_SILU, nullptr, w.emb, u->temb, u->temb, u->temb, B, st));
+    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_SILU, nullptr, w.tproj, u->tp_M, u->tp_M, u->temb, B, st));
+    // conv_in over the virtual concat [x ; cond] (reference diffusion.py:105, unet_1d_condition.py:943)
+    size_t si = 0;
+    {
+        Src s{x, u->M, cond, u->H, T};
+        ConvOpt o;
+        o.pad = 1;
+        LDS_TRY(run_conv(u->conv_in, s, o, w.skips[si], B, st));
+    }
+    const float* cur = w.skips[si++];
+    int Tl = T;
+    std::vector<int> skipT{T};
+    for (int i = 0; i < nb; ++i) {
+        const DownBlk& d = u->down[i];
+        for (size_t j = 0; j < d.res.size(); ++j) {
+            float* dst = w.skips[si];
+            const bool att = !d.att.empty();
+            LDS_TRY(run_resnet(u, d.res[j], w, cur, d.res[j].cin, nullptr, 0, Tl, att ? w.r : dst, B, st));
+            if (att) LDS_TRY(run_tfm(u, d.att[j], w, w.r, Tl, dst, B, st));
+            cur = dst;
+            ++si;
+            skipT.push_back(Tl);
+        }
+        if (d.has_down) {
+            Src s{cur, d.ch, nullptr, 0, Tl};
+            ConvOpt o;
+            o.pad = 1; o.stride = 2;
+            LDS_TRY(run_conv(d.down, s, o, w.skips[si], B, st));
+            Tl = down_len(Tl);
+            cur = w.skips[si++];
+            skipT.push_back(Tl);
+        }
+    }
+    // mid
+    LDS_TRY(run_resnet(u, u->mid_r0, w, cur, u->mid_r0.cin, nullptr, 0, Tl, w.cur[0], B, st));
+    LDS_TRY(run_tfm(u, u->mid_t, w, w.cur[0], Tl, w.cur[1], B, st));
+    LDS_TRY(run_resnet(u, u->mid_r1, w, w.cur[1], u->mid_r1.cin, nullptr, 0, Tl, w.cur[0], B, st));
+    cur = w.cur[0];
+    int ci = 0;  // index of the buffer `cur` lives in
+    for (int i = 0; i < nb; ++i) {
+        const UpBlk& b = u->up[i];
+        for (size_t j = 0; j < b.res.size(); ++j) {
+            --si;
+            const float* skip = w.skips[si];
+            if (skipT[si] != Tl) return fail(LDS_EINVAL, "internal: skip length mismatch");
+            const int hin = b.res[j].cin - b.skip_ch[j];
+            const bool att = !b.att.empty();
+            float* dst = w.cur[ci ^ 1];
+            LDS_TRY(run_resnet(u, b.res[j], w, cur, hin, skip, b.skip_ch[j], Tl, att ? w.r : dst, B, st));
+            if (att) LDS_TRY(run_tfm(u, b.att[j], w, w.r, Tl, dst, B, st));
+            cur = dst;
+            ci ^= 1;
+        }
+        if (b.has_up) {
+            // reference resnet.py:137-173: nearest x2 (or size= of the next skip when T % 2^n != 0) then conv k3
+            const int Tn = skipT[si - 1];
+            float* dst = w.cur[ci ^ 1];
+            ConvOpt o;
+            o.pad = 1;
+            if (Tn == 2 * Tl) {
+                o.ups = 1;
+                Src s{cur, b.ch, nullptr, 0, Tl};
+                LDS_TRY(run_conv(b.up, s, o, dst, B, st));
+            } else {
+                HIP_TRY(launch_resample_nearest(cur, w.upt, B, b.ch, Tl, Tn, st));
+                Src s{w.upt, b.ch, nullptr, 0, Tn};
+                LDS_TRY(run_conv(b.up, s, o, dst, B, st));
+            }
+            Tl = Tn;
+            cur = dst;
+            ci ^= 1;
+        }
+    }
+    // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031)
+    const int c0 = u->cfg.block_out_channels[0];
+    HIP_TRY(launch_gn_coef(cur, cur, c0, 0, Tl, (long long)c0 * Tl, 0, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, w.coef, B, st));
+    Src s{cur, c0, nullptr, 0, Tl};
+    ConvOpt o;
+    o.pad = 1; o.norm_mode = NORM_ROWCOEF; o.coef = w.coef; o.act_in = ACT_SILU;
+    return run_conv(u->conv_out, s, o, eps, B, st);
+}
+
+extern "C" int lds_unet_forward(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
+                                int B, int T, void* stream) {
+    if (!u || !x || !cond || !t || !eps || !ws || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    return unet_forward_impl(u, x, cond, t, eps, ws, ws_bytes, B, T, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// Sampler loops
+// ================================================================================================
+struct SampWs { float *tvec, *eps, *m0, *m1, *m2, *xt, *xp; size_t unet_off; };
+
+static void plan_samp(const lds_unet* u, Arena& A, int B, int T, SampWs& s) {
+    const size_t n = (size_t)B * u->M * T;
+    s.tvec = A.f(B);
+    s.eps = A.f(n); s.m0 = A.f(n); s.m1 = A.f(n); s.m2 = A.f(n); s.xt = A.f(n); s.xp = A.f(n);
+    s.unet_off = A.used;
+}
+
+extern "C" int lds_sampler_workspace_bytes(const lds_unet* u, int B, int T, size_t* out) {
+    if (!u || !out || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    Arena A(nullptr, 0);
+    SampWs s;
+    plan_samp(u, A, B, T, s);
+    size_t un = 0;
+    LDS_TRY(lds_unet_workspace_bytes(u, B, T, &un));
+    *out = A.used + un;
+    return LDS_OK;
+}
+
+extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x,
+                               const float* noise, void* ws, size_t ws_bytes, int B, int T, void* stream) {
+    if (!u || !table || !cond || !x || !ws || n_rows <= 0 || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    Arena A(ws, ws_bytes);
+    SampWs s;
+    plan_samp(u, A, B, T, s);
+    if (!A.ok || A.used > ws_bytes) return fail(LDS_ENOMEM, "sampler workspace too small");
+    void* uws = (char*)ws + s.unet_off;
+    const size_t uws_bytes = ws_bytes - s.unet_off;
+    const long long n = (long long)B * u->M * T;
+    const int S = LDS_TABLE_STRIDE;
+    auto model = [&](const float* xin, float t_in) -> int {
+        HIP_TRY(launch_fill(s.tvec, t_in, B, st));
+        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st);
+    };
+    float *m0 = s.m0, *m1 = s.m1, *m2 = s.m2;
+    if (method == LDS_METHOD_DPM_SOLVER_PP) {
+        // row i: {t_in, sigma_i, alpha_i, order, sigma_{i+1}/sigma_i, alpha_{i+1}*phi, 0.5*that, 1/r0}
+        for (int i = 0; i < n_rows; ++i) {
+            const float* r = table + (size_t)i * S;
+            LDS_TRY(model(x, r[0]));
+            float* tmp = m1; m1 = m0; m0 = tmp;
+            HIP_TRY(launch_ew(EW_X0, m0, x, s.eps, nullptr, nullptr, r[1], r[2], 0, 0, 0, n, st));
+            if (r[3] < 1.5f) HIP_TRY(launch_ew(EW_AXPBY, x, x, m0, nullptr, nullptr, r[4], r[5], 0, 0, 0, n, st));
+            else HIP_TRY(launch_ew(EW_DPM2, x, x, m0, m1, nullptr, r[4], r[5], r[6], r[7], 0, n, st));
+        }
+    } else if (method == LDS_METHOD_UNIPC) {
+        // row 0: {t_in, sigma, alpha}; rows s>=1: {t_in, sigma_s, alpha_s, order, sigma_s/sigma_{s-1}, alpha_s*h_phi_1,
+        //                                         alpha_s*B_h, r_k, rho_p, rho_c0, rho_c1, use_corrector}
+        LDS_TRY(model(x, table[0]));
+        HIP_TRY(launch_ew(EW_X0, m0, x, s.eps, nullptr, nullptr, table[1], table[2], 0, 0, 0, n, st));
+        for (int i = 1; i < n_rows; ++i) {
+            const float* r = table + (size_t)i * S;
+            const bool o2 = r[3] > 1.5f, corr = r[11] > 0.5f;
+            HIP_TRY(launch_ew(EW_AXPBY, s.xt, x, m0, nullptr, nullptr, r[4], r[5], 0, 0, 0, n, st));
+            const float* xpred = s.xt;
+            if (o2) {
+                HIP_TRY(launch_ew(EW_UNIPC_PRED, s.xp, s.xt, m0, m1, nullptr, r[6], r[8], r[7], 0, 0, n, st));
+                xpred = s.xp;
+            }
+            if (corr) {
+                LDS_TRY(model(xpred, r[0]));
+                HIP_TRY(launch_ew(EW_X0, m2, xpred, s.eps, nullptr, nullptr, r[1], r[2], 0, 0, 0, n, st));
+                if (o2) HIP_TRY(launch_ew(EW_UNIPC_CORR, x, s.xt, m0, m2, m1, r[6], r[9], r[7], r[10], 0, n, st));
+                else HIP_TRY(launch_ew(EW_UNIPC_CORR1, x, s.xt, m0, m2, nullptr, r[6], 0, 0, r[10], 0, n, st));
+                float* tmp = m1; m1 = m0; m0 = m2; m2 = tmp;
+            } else {
+                HIP_TRY(launch_ew(EW_COPY, x, xpred, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, n, st));
+            }
+        }
+    } else if (method == LDS_METHOD_DDPM) {
+        // row n: {t, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, mask*exp(0.5*logvar)}
+        if (!noise) return fail(LDS_EINVAL, "DDPM needs per-step noise");
+        for (int i = 0; i < n_rows; ++i) {
+            const float* r = table + (size_t)i * S;
+            LDS_TRY(model(x, r[0]));
+            HIP_TRY(launch_ew(EW_DDPM, x, x, s.eps, noise + (size_t)i * n, nullptr, r[1], r[2], r[3], r[4], r[5], n, st));
+        }
+    } else if (method == LDS_METHOD_DDIM) {
+        // row n: {t, sqrt(a_prev), sqrt(a_t), sqrt((1-a_prev)/a_prev) - sqrt((1-a_t)/a_t)}
+        for (int i = 0; i < n_rows; ++i) {
+            const float* r = table + (size_t)i * S;
+            LDS_TRY(model(x, r[0]));
+            HIP_TRY(launch_ew(EW_DDIM, x, x, s.eps, nullptr, nullptr, r[1], r[2], r[3], 0, 0, n, st));
+        }
+    } else if (method == LDS_METHOD_PLMS) {
+        // row n: {t, t_prev, a_prev - a_t, c1, c2}; eps history in m0 (latest) .. m2, working copy in xt
+        int nh = 0;
+        for (int i = 0; i < n_rows; ++i) {
+            const float* r = table + (size_t)i * S;
+            LDS_TRY(model(x, r[0]));
+            float* e = s.xt;   // keep eps_t
+            HIP_TRY(launch_ew(EW_COPY, e, s.eps, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, n, st));
+            float* ep = s.xp;
+            if (nh == 0) {
+                HIP_TRY(launch_ew(EW_PLMS_PRED, ep, x, e, nullptr, nullptr, r[2], r[3], r[4], 0, 0, n, st));
+                LDS_TRY(model(ep, r[1]));
+                HIP_TRY(launch_ew(EW_LIN4, ep, e, s.eps, nullptr, nullptr, 1.f, 1.f, 0, 0, 2.f, n, st));
+            } else if (nh == 1) {
+                HIP_TRY(launch_ew(EW_LIN4, ep, e, m0, nullptr, nullptr, 3.f, -1.f, 0, 0, 2.f, n, st));
+            } else if (nh == 2) {
+                HIP_TRY(launch_ew(EW_LIN4, ep, e, m0, m1, nullptr, 23.f, -16.f, 5.f, 0, 12.f, n, st));
+            } else {
+                HIP_TRY(launch_ew(EW_LIN4, ep, e, m0, m1, m2, 55.f, -59.f, 37.f, -9.f, 24.f, n, st));
+            }
+            HIP_TRY(launch_ew(EW_PLMS_PRED, x, x, ep, nullptr, nullptr, r[2], r[3], r[4], 0, 0, n, st));
+            float* tmp = m2; m2 = m1; m1 = m0; m0 = tmp;
+            HIP_TRY(launch_ew(EW_COPY, m0, e, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, n, st));
+            if (nh < 3) ++nh;
+        }
+    } else {
+        return fail(LDS_EINVAL, "unknown sampler method %d", method);
+    }
+    return LDS_OK;
+}
+
+// ================================================================================================
+// Front end
+// ================================================================================================
+struct lds_embed {
+    Owner own;
+    int Cin = 0, H = 0, n_spk = 0;
+    ConvW lin;
+    float* spk = nullptr;
+};
+
+extern "C" int lds_embed_create(int input_channel, int n_hidden, int n_spk, const float* unit_w, const float* unit_b,
+                                const float* spk_w, lds_embed** out) {
+    if (!unit_w || !unit_b || !out || input_channel % 16 || n_hidden <= 0) return fail(LDS_EINVAL, "bad argument");
+    lds_embed* e = new lds_embed();
+    e->Cin = input_channel; e->H = n_hidden; e->n_spk = (spk_w && n_spk > 1) ? n_spk : 0;
+    bool ok = pack_conv(e->own, unit_w, unit_b, n_hidden, input_channel, 1, e->lin);
+    if (ok && e->n_spk) { e->spk = up_vec(e->own, spk_w, (int64_t)n_spk * n_hidden); ok = e->spk != nullptr; }
+    if (!ok) { delete e; return fail(LDS_ENOMEM, "embed upload failed"); }
+    *out = e;
+    return LDS_OK;
+}
+extern "C" void lds_embed_destroy(lds_embed* e) { delete e; }
+extern "C" int lds_embed_workspace_bytes(const lds_embed* e, int B, int T, size_t* out) {
+    if (!e || !out) return fail(LDS_EINVAL, "bad argument");
+    Arena A(nullptr, 0);
+    A.f((size_t)B * e->Cin * T);
+    A.f((size_t)B * e->H);
+    *out = A.used;
+    return LDS_OK;
+}
+extern "C" int lds_embed_forward(lds_embed* e, const float* units, const int64_t* spk_id, float* cond, void* ws, size_t ws_bytes,
+                                 int B, int T, void* stream) {
+    if (!e || !units || !cond || !ws) return fail(LDS_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    Arena A(ws, ws_bytes);
+    float* ut = A.f((size_t)B * e->Cin * T);
+    float* sb = A.f((size_t)B * e->H);
+    if (!A.ok) return fail(LDS_ENOMEM, "embed workspace too small");
+    HIP_TRY(launch_transpose(units, ut, B, T, e->Cin, 1.0f, st));          // [B,T,K] -> [B,K,T]
+    ConvOpt o;
+    if (e->n_spk) {
+        if (!spk_id) return fail(LDS_EINVAL, "spk_id required");
+        HIP_TRY(launch_gather_rows(e->spk, spk_id, -1, sb, B, e->H, e->n_spk, st));
+        o.bias_bc = sb;
+    }
+    Src s{ut, e->Cin, nullptr, 0, T};
+    return run_conv(e->lin, s, o, cond, B, st);
+}
+
+extern "C" int lds_transpose(const float* in, float* out, int B, int R, int C, float scale, void* stream) {
+    if (!in || !out) return fail(LDS_EINVAL, "bad argument");
+    HIP_TRY(launch_transpose(in, out, B, R, C, scale, (hipStream_t)stream));
+    return LDS_OK;
+}
+
+extern "C" int lds_axpby(float* out, const float* a, const float* b, float c0, float c1, int64_t n, void* stream) {
+    if (!out || !a || !b || n <= 0) return fail(LDS_EINVAL, "bad argument");
+    HIP_TRY(launch_ew(EW_AXPBY, out, a, b, nullptr, nullptr, c0, -c1, 0, 0, 0, n, (hipStream_t)stream));
+    return LDS_OK;
+}
+
+// ================================================================================================
+// Vocoder
+// ================================================================================================
+struct VocRes { std::vector<ConvW> c1, c2; int k = 3; std::vector<int> dil; };
+struct lds_vocoder {
+    lds_vocoder_cfg cfg;
+    Owner own;
+    ConvW pre, post;
+    std::vector<ConvW> ups;
+    std::vector<VocRes> rbs;
+};
+
+// fold weight norm: w = g * v / ||v|| (norm over all dims but 0), reference hifi_vaegan.py:61
+static bool get_folded(Tensors& T, const std::string& p, int64_t d0, int64_t rest, std::vector<float>& out) {
+    if (T.has(p + "weight")) {
+        const float* w = T.get(p + "weight", d0 * rest);
+        if (!w) return false;
+        out.assign(w, w + d0 * rest);
+        return true;
+    }
+    const float* g = T.get(p + "weight_g", d0);
+    const float* v = T.get(p + "weight_v", d0 * rest);
+    if (!g || !v) return false;
+    out.resize(d0 * rest);
+    for (int64_t i = 0; i < d0; ++i) {
+        double ss = 0;
+        for (int64_t j = 0; j < rest; ++j) ss += (double)v[i * rest + j] * v[i * rest + j];
+        const float sc = g[i] / (float)sqrt(ss);
+        for (int64_t j = 0; j < rest; ++j) out[i * rest + j] = v[i * rest + j] * sc;
+    }
+    return true;
+}
+
+extern "C" int lds_vocoder_create(const lds_vocoder_cfg* cfg, int n, const char* const* names, const float* const* ptrs,
+                                  const int64_t* numel, lds_vocoder** out) {
+    if (!cfg || !names || !ptrs || !numel || !out) return fail(LDS_EINVAL, "null argument");
+    if (cfg->n_ups < 1 || cfg->n_ups > 8 || cfg->n_kernels < 1 || cfg->n_kernels > 4 || cfg->n_dil < 1 || cfg->n_dil > 4)
+        return fail(LDS_EINVAL, "vocoder config out of range");
+    Tensors T;
+    for (int i = 0; i < n; ++i) T.m[names[i]] = {ptrs[i], numel[i]};
+    lds_vocoder* v = new lds_vocoder();
+    v->cfg = *cfg;
+    Owner& o = v->own;
+    bool ok = true;
+    std::vector<float> w;
+    const int c0 = cfg->upsample_initial_channel, ci = cfg->inter_channels;
+    if (ci % 16) { delete v; return fail(LDS_EINVAL, "inter_channels must be a multiple of 16"); }
+    ok = get_folded(T, "conv_pre.", c0, (int64_t)ci * 7, w) && pack_conv(o, w.data(), T.get("conv_pre.bias", c0), c0, ci, 7, v->pre);
+    int ch = c0;
+    for (int i = 0; i < cfg->n_ups && ok; ++i) {
+        const int cin = c0 >> i, cout = c0 >> (i + 1), k = cfg->upsample_kernel_sizes[i], s = cfg->upsample_rates[i];
+        if (cout < 16 || (cout % 16) || k % s != 0 || ((k - s) % 2) != 0) { ok = false; T.missing = "unsupported upsample geometry"; break; }
+        const std::string p = "ups." + std::to_string(i) + ".";
+        ConvW cw;
+        ok = get_folded(T, p, cin, (int64_t)cout * k, w) && pack_convT(o, w.data(), T.get(p + "bias", cout), cin, cout, k, s, cw);
+        v->ups.push_back(cw);
+        ch = cout;
+        for (int j = 0; j < cfg->n_kernels && ok; ++j) {
+            VocRes rb;
+            rb.k = cfg->resblock_kernel_sizes[j];
+            if (rb.k != 3 && rb.k != 7 && rb.k != 11) { ok = false; T.missing = "resblock kernel size must be 3, 7 or 11"; break; }
+            const std::string rp = "resblocks." + std::to_string(i * cfg->n_kernels + j) + ".";
+            for (int m = 0; m < cfg->n_dil && ok; ++m) {
+                rb.dil.push_back(cfg->resblock_dilation_sizes[j][m]);
+                if (rb.dil.back() < 1 || rb.dil.back() > 5) { ok = false; T.missing = "dilation must be 1..5"; break; }
+                ConvW a, b;
+                if (cfg->resblock == 1) {
+                    const std::string p1 = rp + "convs1." + std::to_string(m) + ".", p2 = rp + "convs2." + std::to_string(m) + ".";
+                    ok = get_folded(T, p1, ch, (int64_t)ch * rb.k, w) && pack_conv(o, w.data(), T.get(p1 + "bias", ch), ch, ch, rb.k, a);
+                    ok = ok && get_folded(T, p2, ch, (int64_t)ch * rb.k, w) && pack_conv(o, w.data(), T.get(p2 + "bias", ch), ch, ch, rb.k, b);
+                    rb.c1.push_back(a);
+                    rb.c2.push_back(b);
+                } else {
+                    const std::string p1 = rp + "convs." + std::to_string(m) + ".";
+                    ok = get_folded(T, p1, ch, (int64_t)ch * rb.k, w) && pack_conv(o, w.data(), T.get(p1 + "bias", ch), ch, ch, rb.k, a);
+                    rb.c1.push_back(a);
+                }
+            }
+            v->rbs.push_back(rb);
+        }
+    }
+    ok = ok && get_folded(T, "conv_post.", 1, (int64_t)ch * 7, w) && pack_conv(o, w.data(), T.get("conv_post.bias", 1), 1, ch, 7, v->post);
+    if (!ok) {
+        std::string miss = T.missing;
+        delete v;
+        if (!miss.empty()) return fail(LDS_EMISSING, "vocoder: %s", miss.c_str());
+        return fail(LDS_ENOMEM, "vocoder weight upload failed");
+    }
+    *out = v;
+    return LDS_OK;
+}
+extern "C" void lds_vocoder_destroy(lds_vocoder* v) { delete v; }
+
+struct VocWs { float *x, *xs, *ta, *ra, *rb; };
+static void plan_voc(const lds_vocoder* v, Arena& A, int B, int T, VocWs& w) {
+    size_t mx = (size_t)v->cfg.upsample_initial_channel * T;
+    int Tl = T;
+    for (int i = 0; i < v->cfg.n_ups; ++i) {
+        Tl *= v->cfg.upsample_rates[i];
+        const size_t ct = (size_t)(v->cfg.upsample_initial_channel >> (i + 1)) * Tl;
+        if (ct > mx) mx = ct;
+    }
+    w.x = A.f(B * mx); w.xs = A.f(B * mx); w.ta = A.f(B * mx); w.ra = A.f(B * mx); w.rb = A.f(B * mx);
+}
+extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out) {
+    if (!v || !out || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    Arena A(nullptr, 0);
+    VocWs w;
+    plan_voc(v, A, B, T, w);
+    *out = A.used;
+    return LDS_OK;
+}
+
+extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream) {
+    if (!v || !z || !wav || !ws || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    Arena A(ws, ws_bytes);
+    VocWs w;
+    plan_voc(v, A, B, T, w);
+    if (!A.ok) return fail(LDS_ENOMEM, "vocoder workspace too small: need %zu", A.used);
+    const lds_vocoder_cfg& c = v->cfg;
+    // reference models.py:248-262
+    {
+        Src s{z, c.inter_channels, nullptr, 0, T};
+        ConvOpt o;
+        o.pad = 3;
+        LDS_TRY(run_conv(v->pre, s, o, w.x, B, st));
+    }
+    int ch = c.upsample_initial_channel, Tl = T;
+    float* x = w.x;
+    float* xs = w.xs;
+    for (int i = 0; i < c.n_ups; ++i) {
+        const int s_ = c.upsample_rates[i], k = c.upsample_kernel_sizes[i], cout = ch / 2;
+        const int Tn = (Tl - 1) * s_ - 2 * ((k - s_ + 1) / 2) + k;
+        {
+            // x = ups[i](leaky_relu(x, 0.1)) as a polyphase conv
+            Src s{x, ch, nullptr, 0, Tl};
+            ConvOpt o;
+            o.pad = v->ups[i].K - 1; o.act_in = ACT_LRELU; o.slope = 0.1f;
+            o.phases = s_; o.tpad = (k - s_ + 1) / 2; o.To = Tl + 1; o.Tout = Tn; o.Cout = cout;
+            LDS_TRY(run_conv(v->ups[i], s, o, xs, B, st));
+        }
+        { float* t = x; x = xs; xs = t; }
+        ch = cout; Tl = Tn;
+        for (int j = 0; j < c.n_kernels; ++j) {
+            const VocRes& rb = v->rbs[i * c.n_kernels + j];
+            const float* cur = x;
+            float* pp[2] = {w.ra, w.rb};
+            const int nd = (int)rb.dil.size();
+            for (int m = 0; m < nd; ++m) {
+                const bool last = m == nd - 1;
+                const int d = rb.dil[m];
+                Src s1{cur, ch, nullptr, 0, Tl};
+                ConvOpt o1;
+                o1.dil = d; o1.pad = (rb.k * d - d) / 2; o1.act_in = ACT_LRELU; o1.slope = 0.1f;
+                ConvOpt o2;
+                o2.res = cur;
+                if (last) { o2.accum = j > 0; o2.out_div = (j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f; }
+                float* dst = last ? xs : pp[m & 1];
+                if (c.resblock == 1) {
+                    LDS_TRY(run_conv(rb.c1[m], s1, o1, w.ta, B, st));
+                    Src s2{w.ta, ch, nullptr, 0, Tl};
+                    o2.pad = (rb.k - 1) / 2; o2.act_in = ACT_LRELU; o2.slope = 0.1f;
+                    LDS_TRY(run_conv(rb.c2[m], s2, o2, dst, B, st));
+                } else {
+                    o2.dil = d; o2.pad = o1.pad; o2.act_in = ACT_LRELU; o2.slope = 0.1f;
+                    LDS_TRY(run_conv(rb.c1[m], s1, o2, dst, B, st));
+                }
+                cur = dst;
+            }
+        }
+        { float* t = x; x = xs; xs = t; }
+    }
+    Src s{x, ch, nullptr, 0, Tl};
+    ConvOpt o;
+    o.pad = 3; o.act_in = ACT_LRELU; o.slope = 0.01f; o.epi = EPI_TANH;
+    return run_conv(v->post, s, o, wav, B, st);
+}
+
+// ================================================================================================
+// Single-op test entry points
+// ================================================================================================
+extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream) {
+    if (!a || !out) return fail(LDS_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    ConvW W;
+    const int Ci = a->C1 + a->C2;
+    bool ok;
+    if (a->epilogue == EPI_GEGLU) ok = pack_geglu(own, a->w, a->bias, a->Co, Ci, W);
+    else ok = pack_conv(own, a->w, a->bias, a->Co, Ci, a->K, W);
+    if (!ok) return fail(LDS_ENOMEM, "test conv: upload failed");
+    const int T = a->Tsrc;
+    void* tmp = nullptr;
+    const size_t coef_b = (size_t)B * Ci * sizeof(float4), st_b = (size_t)B * T * sizeof(float);
+    HIP_TRY(hipMalloc(&tmp, coef_b + 2 * st_b + 1024));
+    own.ptrs.push_back(tmp);
+    float4* coef = (float4*)tmp;
+    float* lm = (float*)((char*)tmp + coef_b);
+    float* lr = lm + (size_t)B * T;
+    float *g = nullptr, *be = nullptr;
+    if (a->norm_mode) {
+        g = up_vec(own, a->gamma, Ci);
+        be = up_vec(own, a->beta, Ci);
+        if (!g || !be) return fail(LDS_ENOMEM, "test conv: upload failed");
+    }
+    ConvOpt o;
+    o.stride = a->stride; o.pad = a->pad; o.dil = a->dil; o.ups = a->upsample2x;
+    o.act_in = a->act_in; o.slope = a->slope; o.res = a->res; o.epi = a->epilogue; o.tile = a->tile;
+    if (a->norm_mode == NORM_ROWCOEF) {
+        HIP_TRY(launch_gn_coef(a->x1, a->x2 ? a->x2 : a->x1, a->C1, a->C2, T, (long long)a->C1 * T, (long long)a->C2 * T, a->groups, a->eps,
+                               g, be, a->scale_shift, 2 * Ci, 0, coef, B, st));
+        o.norm_mode = NORM_ROWCOEF; o.coef = coef;
+    } else if (a->norm_mode == NORM_COLSTAT) {
+        if (a->C2) return fail(LDS_EINVAL, "LayerNorm test takes a single source");
+        HIP_TRY(launch_ln_stats(a->x1, Ci, T, a->eps, lm, lr, B, st));
+        o.norm_mode = NORM_COLSTAT; o.cmean = lm; o.crstd = lr; o.gamma = g; o.beta = be;
+    }
+    Src s{a->x1, a->C1, a->x2, a->C2, T};
+    int r = run_conv(W, s, o, out, B, st);
+    HIP_TRY(hipStreamSynchronize(st));   // test-only entry point: temporaries are freed on return
+    return r;
+}
+
+extern "C" int lds_test_attention(const float* qkv, float* out, int B, int C, int T, int heads, void* stream) {
+    HIP_TRY(launch_attention(qkv, out, B, C, T, heads, (hipStream_t)stream));
+    return LDS_OK;
+}
+
+extern "C" int lds_test_conv_transpose(const float* x, const float* w, const float* bias, float* out, int B, int Ci, int Co, int T, int K,
+                                       int stride, int pad, float in_slope, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (K % stride || pad != (K - stride + 1) / 2) return fail(LDS_EINVAL, "unsupported transposed-conv geometry");
+    Owner own;
+    ConvW W;
+    if (!pack_convT(own, w, bias, Ci, Co, K, stride, W)) return fail(LDS_ENOMEM, "upload failed");
+    Src s{x, Ci, nullptr, 0, T};
+    ConvOpt o;
+    o.pad = W.K - 1; o.phases = stride; o.tpad = pad; o.To = T + 1; o.Tout = (T - 1) * stride - 2 * pad + K; o.Cout = Co;
+    if (in_slope != 1.0f) { o.act_in = ACT_LRELU; o.slope = in_slope; }
+    int r = run_conv(W, s, o, out, B, st);
+    HIP_TRY(hipStreamSynchronize(st));
+    return r;
+}

@@ -1,0 +1,65 @@
+"""`UNet1DConditionModel` with the reference's constructor keywords, state_dict keys and
+`.forward(sample, timestep).sample` contract (reference diffusion/unet1d/unet_1d_condition.py:61,
+743-1036), executed by liblds (hand-written gfx950 kernels).  Only the configuration Unit2Mel
+uses is supported (reference diffusion/unit2mel.py:62-71); anything else raises."""
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from lds import arch, native
+from lds.paramtree import ParamTree
+
+
+@dataclass
+class UNet1DConditionOutput:
+    """reference unet_1d_condition.py:48-58 (a BaseOutput with a `.sample` field)"""
+    sample: torch.FloatTensor = None
+
+
+class UNet1DConditionModel(ParamTree):
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), norm_num_groups=32,
+                 cross_attention_dim=1280, attention_head_dim=8, only_cross_attention=False, layers_per_block=2,
+                 resnet_time_scale_shift="default", cond_channels=None, **unsupported):
+        if unsupported:
+            raise NotImplementedError(f"UNet1DConditionModel options not on the hot path: {sorted(unsupported)}")
+        if resnet_time_scale_shift != "scale_shift" or not only_cross_attention:
+            raise NotImplementedError("only the Unit2Mel configuration (scale_shift, only_cross_attention) is built")
+        boc = tuple(int(c) for c in block_out_channels)
+        if tuple(cross_attention_dim) != boc:
+            raise NotImplementedError("cross_attention_dim must equal block_out_channels (self-attention, SURVEY F7)")
+        if cond_channels is None:
+            cond_channels = in_channels - out_channels
+        cfg = arch.unet_config(out_dims=out_channels, n_hidden=cond_channels, block_out_channels=boc,
+                               n_layers=layers_per_block, n_heads=attention_head_dim, norm_groups=norm_num_groups)
+        super().__init__(arch.unet_param_shapes(cfg), seed=0)
+        self.cfg = cfg
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._native = None
+
+    # any change of the parameters (load_state_dict, .to(), manual edits via _apply) drops the packed copy
+    def _apply(self, fn, *a, **k):
+        self._native = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._native = None
+        return super().load_state_dict(*a, **k)
+
+    def native(self):
+        if self._native is None:
+            self._native = native.UNet(self.cfg, {k: v for k, v in self.state_dict().items()})
+        return self._native
+
+    def forward(self, sample, timestep, **kwargs):
+        """sample [B, M+H, T] (x stacked on cond, reference diffusion.py:105), timestep [B] or scalar."""
+        if any(v is not None for v in kwargs.values()):
+            raise NotImplementedError(f"unsupported forward arguments {sorted(kwargs)}")
+        B = sample.shape[0]
+        M = self.out_channels
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], device=sample.device)
+        t = timestep.reshape(-1).to(device=sample.device, dtype=torch.float32).expand(B).contiguous()
+        x = sample[:, :M].contiguous()
+        cond = sample[:, M:].contiguous()
+        return UNet1DConditionOutput(sample=self.native().forward(x, cond, t))

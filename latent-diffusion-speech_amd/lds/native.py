@@ -1,0 +1,257 @@
+"""ctypes binding of liblds.so (include/lds.h).  PyTorch is used only to own device memory and
+the HIP stream; every arithmetic op of the hot path runs inside the library.  There is no CPU
+fallback: if the shared object is missing or a tensor is not on a HIP device the call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblds.so")
+_lib = None
+
+METHODS = {"dpm-solver": 1, "unipc": 2, "ddpm": 3, "ddim": 4, "pndm": 5}
+TABLE_STRIDE = 16
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("out_dims", C.c_int), ("n_hidden", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int),
+                ("norm_groups", C.c_int), ("n_blocks", C.c_int), ("block_out_channels", C.c_int * 8)]
+
+
+class VocoderCfg(C.Structure):
+    _fields_ = [("inter_channels", C.c_int), ("upsample_initial_channel", C.c_int), ("n_ups", C.c_int),
+                ("upsample_rates", C.c_int * 8), ("upsample_kernel_sizes", C.c_int * 8), ("resblock", C.c_int),
+                ("n_kernels", C.c_int), ("resblock_kernel_sizes", C.c_int * 4), ("n_dil", C.c_int),
+                ("resblock_dilation_sizes", (C.c_int * 4) * 4)]
+
+
+class ConvTest(C.Structure):
+    _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("C1", C.c_int), ("C2", C.c_int), ("Tsrc", C.c_int),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("Co", C.c_int), ("K", C.c_int), ("stride", C.c_int),
+                ("pad", C.c_int), ("dil", C.c_int), ("upsample2x", C.c_int), ("norm_mode", C.c_int),
+                ("groups", C.c_int), ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("scale_shift", C.c_void_p), ("act_in", C.c_int), ("slope", C.c_float), ("res", C.c_void_p),
+                ("epilogue", C.c_int), ("tile", C.c_int)]
+
+
+EXPORTS = [
+    "lds_last_error", "lds_version", "lds_unet_create", "lds_unet_destroy", "lds_unet_workspace_bytes",
+    "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
+    "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
+    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_test_conv", "lds_test_attention",
+    "lds_test_conv_transpose"]
+
+
+def lib():
+    """Load liblds.so (once).  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C latent-diffusion-speech_amd/csrc` "
+                               "(there is no CPU fallback for the hot path)")
+        L = C.CDLL(LIB_PATH)
+        L.lds_last_error.restype = C.c_char_p
+        for n in EXPORTS:
+            if n not in ("lds_last_error", "lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy"):
+                getattr(L, n).restype = C.c_int
+        for n in ("lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy"):
+            getattr(L, n).restype = None
+            getattr(L, n).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"liblds error {rc}: {lib().lds_last_error().decode()}")
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=None):
+    """Device pointer of a contiguous tensor that must live on the GPU."""
+    import torch
+    if not t.is_cuda:
+        raise RuntimeError("liblds needs tensors on a HIP device (no CPU fallback for the hot path)")
+    if not t.is_contiguous():
+        raise RuntimeError("liblds needs contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _host_tensor_table(state):
+    """state: name -> fp32 numpy/torch (CPU).  Returns ctypes arrays + keep-alive list."""
+    names, ptrs, numel, keep = [], [], [], []
+    for k, v in state.items():
+        a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        keep.append(a)
+        names.append(k.encode())
+        ptrs.append(a.ctypes.data)
+        numel.append(a.size)
+    n = len(names)
+    return (n, (C.c_char_p * n)(*names), (C.c_void_p * n)(*ptrs), (C.c_int64 * n)(*numel), keep)
+
+
+class Workspace:
+    """A growable device scratch buffer owned by torch (one per handle; grown on demand)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        import torch
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class UNet:
+    """Handle on the packed denoiser (lds_unet_*)."""
+
+    def __init__(self, cfg, state):
+        c = UNetCfg()
+        c.out_dims, c.n_hidden = cfg["out_channels"], cfg["cond_channels"]
+        c.n_layers, c.n_heads, c.norm_groups = cfg["layers_per_block"], cfg["heads"], cfg["groups"]
+        boc = cfg["block_out_channels"]
+        c.n_blocks = len(boc)
+        for i, v in enumerate(boc):
+            c.block_out_channels[i] = v
+        n, names, ptrs, numel, keep = _host_tensor_table(state)
+        self.h = C.c_void_p()
+        check(lib().lds_unet_create(C.byref(c), n, names, ptrs, numel, C.byref(self.h)))
+        self.M, self.H = c.out_dims, c.n_hidden
+        self.ws = Workspace()
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.lds_unet_destroy(self.h)
+            self.h = None
+
+    def forward(self, x, cond, t):
+        import torch
+        B, M, T = x.shape
+        assert M == self.M and cond.shape == (B, self.H, T) and t.shape == (B,)
+        nb = C.c_size_t()
+        check(lib().lds_unet_workspace_bytes(self.h, B, T, C.byref(nb)))
+        ws = self.ws.get(nb.value, x.device)
+        eps = torch.empty_like(x)
+        check(lib().lds_unet_forward(self.h, _dev(x, torch.float32), _dev(cond, torch.float32), _dev(t, torch.float32),
+                                     _dev(eps), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
+        return eps
+
+    def sample(self, method, table, cond, x, noise=None):
+        """Run a whole sampler loop in place on x [B,M,T]; table: float32 [n_rows, 16] (host)."""
+        import torch
+        B, M, T = x.shape
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        assert table.ndim == 2 and table.shape[1] == TABLE_STRIDE
+        nb = C.c_size_t()
+        check(lib().lds_sampler_workspace_bytes(self.h, B, T, C.byref(nb)))
+        ws = self.ws.get(nb.value, x.device)
+        check(lib().lds_sampler_run(self.h, METHODS[method], table.shape[0], C.c_void_p(table.ctypes.data),
+                                    _dev(cond, torch.float32), _dev(x, torch.float32),
+                                    _dev(noise, torch.float32) if noise is not None else None, _dev(ws),
+                                    C.c_size_t(ws.numel()), B, T, _stream()))
+        return x
+
+
+class Embed:
+    """unit_embed + spk_embed front end (lds_embed_*)."""
+
+    def __init__(self, unit_w, unit_b, spk_w=None):
+        uw = np.ascontiguousarray(unit_w, dtype=np.float32)
+        ub = np.ascontiguousarray(unit_b, dtype=np.float32)
+        sw = None if spk_w is None else np.ascontiguousarray(spk_w, dtype=np.float32)
+        self.H, self.Cin = uw.shape
+        self.h = C.c_void_p()
+        check(lib().lds_embed_create(self.Cin, self.H, 0 if sw is None else sw.shape[0], C.c_void_p(uw.ctypes.data),
+                                     C.c_void_p(ub.ctypes.data), None if sw is None else C.c_void_p(sw.ctypes.data),
+                                     C.byref(self.h)))
+        self.ws = Workspace()
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.lds_embed_destroy(self.h)
+            self.h = None
+
+    def forward(self, units, spk_id):
+        import torch
+        B, T, K = units.shape
+        assert K == self.Cin
+        nb = C.c_size_t()
+        check(lib().lds_embed_workspace_bytes(self.h, B, T, C.byref(nb)))
+        ws = self.ws.get(nb.value, units.device)
+        cond = torch.empty(B, self.H, T, dtype=torch.float32, device=units.device)
+        sid = None
+        if spk_id is not None:
+            sid = spk_id.reshape(B, -1)[:, 0].contiguous().to(torch.int64)
+        check(lib().lds_embed_forward(self.h, _dev(units, torch.float32), _dev(sid) if sid is not None else None,
+                                      _dev(cond), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
+        return cond
+
+
+def axpby(a, b, c0, c1):
+    """c0*a + c1*b on the device."""
+    import torch
+    out = torch.empty_like(a)
+    check(lib().lds_axpby(_dev(out), _dev(a, torch.float32), _dev(b, torch.float32), C.c_float(c0), C.c_float(c1),
+                          C.c_int64(a.numel()), _stream()))
+    return out
+
+
+def transpose(x, scale=1.0):
+    """[B,R,C] -> [B,C,R] / scale on the device."""
+    import torch
+    B, R, Cc = x.shape
+    out = torch.empty(B, Cc, R, dtype=torch.float32, device=x.device)
+    check(lib().lds_transpose(_dev(x, torch.float32), _dev(out), B, R, Cc, C.c_float(scale), _stream()))
+    return out
+
+
+class Generator:
+    """HiFi-VAEGAN decoder (lds_vocoder_*)."""
+
+    def __init__(self, h, state):
+        c = VocoderCfg()
+        c.inter_channels = h["inter_channels"]
+        c.upsample_initial_channel = h["upsample_initial_channel"]
+        c.n_ups = len(h["upsample_rates"])
+        for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+            c.upsample_rates[i], c.upsample_kernel_sizes[i] = u, k
+        c.resblock = 1 if str(h["resblock"]) == "1" else 2
+        c.n_kernels = len(h["resblock_kernel_sizes"])
+        c.n_dil = len(h["resblock_dilation_sizes"][0])
+        for j, (k, dil) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            c.resblock_kernel_sizes[j] = k
+            for m, d in enumerate(dil):
+                c.resblock_dilation_sizes[j][m] = d
+        n, names, ptrs, numel, keep = _host_tensor_table(state)
+        self.h = C.c_void_p()
+        check(lib().lds_vocoder_create(C.byref(c), n, names, ptrs, numel, C.byref(self.h)))
+        self.hop = int(np.prod(h["upsample_rates"]))
+        self.C = c.inter_channels
+        self.ws = Workspace()
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.lds_vocoder_destroy(self.h)
+            self.h = None
+
+    def forward(self, z):
+        """z [B,C,T] -> wav [B,1,T*hop]"""
+        import torch
+        B, Cc, T = z.shape
+        assert Cc == self.C
+        nb = C.c_size_t()
+        check(lib().lds_vocoder_workspace_bytes(self.h, B, T, C.byref(nb)))
+        ws = self.ws.get(nb.value, z.device)
+        wav = torch.empty(B, 1, T * self.hop, dtype=torch.float32, device=z.device)
+        check(lib().lds_vocoder_forward(self.h, _dev(z, torch.float32), _dev(wav), _dev(ws), C.c_size_t(ws.numel()), B, T,
+                                        _stream()))
+        return wav

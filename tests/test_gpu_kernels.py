@@ -1,0 +1,244 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel of liblds against the numpy oracle
+(itself pinned to the reference's leaf modules by test_oracle_vs_golden.py).  All calls go
+through the C ABI (ctypes).  Tolerances: the kernels compute in exact fp32 (v_mfma_f32_32x32x2
+is a k-ordered fmaf chain), so differences against the oracle are summation-order only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def U(name, shape, lo=-1.0, hi=1.0):
+    from lds import init_weights
+    return init_weights.uniform("t." + name, shape, 7, lo, hi)
+
+
+def run_conv(x1, w, bias=None, x2=None, stride=1, pad=0, dil=1, ups=0, norm=0, groups=8, eps=1e-5, gamma=None, beta=None,
+             ss=None, act=0, slope=0.0, res=None, epi=0, tile=0):
+    from lds import native
+    L = native.lib()
+    B, C1, T = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    Co, _, K = w.shape
+    a = native.ConvTest()
+    dx1 = dev(x1)
+    dx2 = dev(x2) if x2 is not None else None
+    keep = [np.ascontiguousarray(w, dtype=np.float32)]
+    a.x1 = dx1.data_ptr()
+    a.x2 = dx2.data_ptr() if dx2 is not None else None
+    a.C1, a.C2, a.Tsrc = C1, C2, T
+    a.w = keep[0].ctypes.data
+    if bias is not None:
+        keep.append(np.ascontiguousarray(bias, dtype=np.float32))
+        a.bias = keep[-1].ctypes.data
+    a.Co, a.K, a.stride, a.pad, a.dil, a.upsample2x = Co, K, stride, pad, dil, ups
+    a.norm_mode, a.groups, a.eps = norm, groups, eps
+    if norm:
+        keep += [np.ascontiguousarray(gamma, dtype=np.float32), np.ascontiguousarray(beta, dtype=np.float32)]
+        a.gamma, a.beta = keep[-2].ctypes.data, keep[-1].ctypes.data
+    dss = dev(ss) if ss is not None else None
+    a.scale_shift = dss.data_ptr() if dss is not None else None
+    a.act_in, a.slope = act, slope
+    Tin = 2 * T if ups else T
+    To = (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    Cout = Co // 2 if epi == 1 else Co
+    dres = dev(res) if res is not None else None
+    a.res = dres.data_ptr() if dres is not None else None
+    a.epilogue, a.tile = epi, tile
+    out = torch.full((B, Cout, To), float("nan"), dtype=torch.float32, device="cuda")
+    native.check(L.lds_test_conv(C.byref(a), C.c_void_p(out.data_ptr()), B, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def ref_conv(x1, w, bias=None, x2=None, stride=1, pad=0, dil=1, ups=0, norm=0, groups=8, eps=1e-5, gamma=None, beta=None,
+             ss=None, act=0, slope=0.0, res=None, epi=0):
+    from oracle import unet1d
+    from scipy.special import erf
+    x = x1 if x2 is None else np.concatenate([x1, x2], axis=1)
+    if norm == 1:
+        x = unet1d.group_norm(x, gamma, beta, groups, eps)
+        if ss is not None:
+            Cc = x.shape[1]
+            x = (x * (1 + ss[:, :Cc, None]) + ss[:, Cc:, None]).astype(np.float32)
+    elif norm == 2:
+        x = unet1d.layer_norm(x.transpose(0, 2, 1), gamma, beta, eps).transpose(0, 2, 1)
+    if act == 1:
+        x = unet1d.silu(x)
+    elif act == 2:
+        x = np.where(x >= 0, x, x * np.float32(slope)).astype(np.float32)
+    if ups:
+        x = np.repeat(x, 2, axis=-1)
+    y = unet1d.conv1d(np.ascontiguousarray(x), w, bias, stride=stride, pad=pad, dil=dil)
+    if epi == 1:
+        a, g = np.split(y, 2, axis=1)
+        y = (a * (0.5 * g * (1 + erf(g / np.sqrt(2.0))))).astype(np.float32)
+    if res is not None:
+        y = y + res
+    if epi == 2:
+        y = np.tanh(y)
+    return y.astype(np.float32)
+
+
+CONV_CASES = {
+    # name: (B, C1, C2, T, Co, K, kwargs)
+    "1x1_small": (2, 64, 0, 64, 64, 1, {}),
+    "1x1_t128": (1, 256, 0, 128, 256, 1, dict(tile=128128)),
+    "1x1_t12864": (2, 128, 0, 96, 128, 1, dict(tile=128064)),
+    "1x1_res_bias": (2, 96, 0, 80, 192, 1, dict(use_bias=True, use_res=True)),
+    "k3_pad": (2, 64, 0, 64, 64, 3, dict(pad=1, use_bias=True)),
+    "k3_ragged_T": (2, 80, 0, 50, 128, 3, dict(pad=1, use_bias=True)),
+    "k3_odd_T": (1, 32, 0, 37, 64, 3, dict(pad=1)),
+    "k3_t128": (1, 128, 0, 256, 128, 3, dict(pad=1, tile=128128, use_bias=True)),
+    "k3_concat": (2, 64, 48, 72, 128, 3, dict(pad=1, use_bias=True)),
+    "k3_stride2": (2, 64, 0, 64, 64, 3, dict(pad=1, stride=2, use_bias=True)),
+    "k3_stride2_odd": (2, 64, 0, 45, 64, 3, dict(pad=1, stride=2)),
+    "k3_ups": (2, 64, 0, 40, 64, 3, dict(pad=1, ups=1, use_bias=True)),
+    "k3_ups_long": (1, 32, 0, 100, 64, 3, dict(pad=1, ups=1)),
+    "gn_silu_k3": (2, 64, 0, 64, 64, 3, dict(pad=1, norm=1, act=1, use_bias=True)),
+    "gn_concat_straddle": (2, 64, 48, 48, 64, 3, dict(pad=1, norm=1, act=1)),     # 112 ch / 8 groups = 14 ch straddling sources
+    "gn_scale_shift": (2, 128, 0, 64, 128, 3, dict(pad=1, norm=1, act=1, use_ss=True, use_res=True, use_bias=True)),
+    "gn_1x1_eps6": (2, 64, 0, 56, 64, 1, dict(norm=1, eps=1e-6, use_bias=True)),
+    "ln_1x1": (2, 64, 0, 72, 192, 1, dict(norm=2)),
+    "ln_geglu": (2, 64, 0, 64, 512, 1, dict(norm=2, epi=1, use_bias=True, tile=128064)),
+    "geglu_128": (1, 32, 0, 256, 256, 1, dict(epi=1, use_bias=True, tile=128128)),
+    "co80_k3": (2, 64, 0, 64, 80, 3, dict(pad=1, norm=1, act=1, use_bias=True)),
+    "voc_k7": (1, 80, 0, 40, 128, 7, dict(pad=3, use_bias=True)),
+    "voc_k3_d3": (1, 64, 0, 200, 64, 3, dict(pad=3, dil=3, act=2, slope=0.1, use_bias=True)),
+    "voc_k7_d5": (1, 64, 0, 300, 64, 7, dict(pad=15, dil=5, act=2, slope=0.1, use_bias=True, use_res=True)),
+    "voc_k11_d5": (1, 32, 0, 300, 32, 11, dict(pad=25, dil=5, act=2, slope=0.1, use_bias=True, use_res=True)),
+    "voc_k11_d1_c16": (2, 16, 0, 500, 16, 11, dict(pad=5, act=2, slope=0.1, use_bias=True)),
+    "voc_k11_64128": (1, 64, 0, 300, 64, 11, dict(pad=15, dil=3, act=2, slope=0.1, tile=64128)),
+    "voc_post_tanh": (2, 16, 0, 300, 1, 7, dict(pad=3, act=2, slope=0.01, epi=2, use_bias=True)),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_gemm(name):
+    _need_gpu()
+    B, C1, C2, T, Co, K, kw = CONV_CASES[name]
+    kw = dict(kw)
+    x1 = U(name + ".x1", (B, C1, T), -2, 2)
+    x2 = U(name + ".x2", (B, C2, T), -2, 2) if C2 else None
+    Ci = C1 + C2
+    w = U(name + ".w", (Co, Ci, K), -1, 1) / np.float32(np.sqrt(Ci * K))
+    args = dict(x2=x2)
+    if kw.pop("use_bias", False):
+        args["bias"] = U(name + ".b", (Co,))
+    for k in ("stride", "pad", "dil", "ups", "norm", "eps", "act", "slope", "epi"):
+        if k in kw:
+            args[k] = kw[k]
+    if args.get("norm"):
+        args["gamma"] = U(name + ".g", (Ci,), 0.5, 1.5)
+        args["beta"] = U(name + ".be", (Ci,), -0.5, 0.5)
+    if kw.pop("use_ss", False):
+        args["ss"] = U(name + ".ss", (B, 2 * Ci), -0.5, 0.5)
+    ref0 = ref_conv(x1, w, **args)
+    if kw.pop("use_res", False):
+        args["res"] = U(name + ".res", ref0.shape, -1, 1)
+    ref = ref_conv(x1, w, **args)
+    out = run_conv(x1, w, tile=kw.get("tile", 0), **args)
+    assert out.shape == ref.shape
+    assert np.isfinite(out).all()
+    assert relmax(out, ref) < 2e-5, relmax(out, ref)
+
+
+@pytest.mark.parametrize("C,T,B", [(256, 64, 2), (256, 512, 1), (384, 256, 1), (384, 100, 2), (512, 128, 2), (512, 37, 1), (256, 130, 1)])
+def test_attention(C, T, B):
+    _need_gpu()
+    from lds import native
+    heads = 8
+    d = C // heads
+    qkv = U(f"att{C}.{T}", (B, 3 * C, T), -1.5, 1.5)
+    out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    dq = dev(qkv)
+    native.check(native.lib().lds_test_attention(C.c_void_p(dq.data_ptr()) if False else __import__("ctypes").c_void_p(dq.data_ptr()),
+                                                 __import__("ctypes").c_void_p(out.data_ptr()), B, C, T, heads,
+                                                 __import__("ctypes").c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    q, k, v = [qkv[:, i * C:(i + 1) * C].reshape(B, heads, d, T).astype(np.float64) for i in range(3)]
+    s = np.einsum("bhdq,bhdk->bhqk", q, k) / np.sqrt(d)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bhdk->bhdq", p, v).reshape(B, C, T)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max() + 1e-6
+
+
+def test_attention_large_logits():
+    """forces the online-softmax rescale branch: one key dominates late in the sequence"""
+    _need_gpu()
+    from lds import native
+    import ctypes
+    B, C, T, heads = 1, 256, 256, 8
+    d = C // heads
+    qkv = U("attspike", (B, 3 * C, T), -1, 1).copy()
+    qkv[:, C:2 * C, 200] *= 12.0      # spike one key column
+    qkv[:, :C, 5] *= 9.0              # and one query
+    out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    dq = dev(qkv)
+    native.check(native.lib().lds_test_attention(ctypes.c_void_p(dq.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, C, T, heads,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    q, k, v = [qkv[:, i * C:(i + 1) * C].reshape(B, heads, d, T).astype(np.float64) for i in range(3)]
+    s = np.einsum("bhdq,bhdk->bhqk", q, k) / np.sqrt(d)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bhdk->bhdq", p, v).reshape(B, C, T)
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() < 3e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("Ci,Co,T,K,s", [(64, 32, 20, 16, 8), (32, 16, 33, 4, 2), (128, 64, 7, 16, 8), (512, 256, 12, 16, 8)])
+def test_conv_transpose(Ci, Co, T, K, s):
+    _need_gpu()
+    import ctypes
+    from lds import native
+    from oracle import vocoder
+    B = 2
+    pad = (K - s + 1) // 2
+    x = U(f"ct{Ci}.x", (B, Ci, T), -2, 2)
+    w = (U(f"ct{Ci}.w", (Ci, Co, K)) / np.float32(np.sqrt(Ci * K / s))).astype(np.float32)
+    b = U(f"ct{Ci}.b", (Co,))
+    ref = vocoder.conv_transpose1d(vocoder.lrelu(x, 0.1), w, b, s, pad)
+    out = torch.full(ref.shape, float("nan"), dtype=torch.float32, device="cuda")
+    dx = dev(x)
+    native.check(native.lib().lds_test_conv_transpose(ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(w.ctypes.data),
+                                                      ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(out.data_ptr()), B, Ci, Co, T,
+                                                      K, s, pad, ctypes.c_float(0.1),
+                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert relmax(got, ref) < 2e-5
+
+
+def test_transpose_and_axpby():
+    _need_gpu()
+    from lds import native
+    x = U("tr", (3, 45, 70))
+    y = native.transpose(dev(x), 2.0).cpu().numpy()
+    assert np.array_equal(y, (x.transpose(0, 2, 1) / np.float32(2.0)))
+    a, b = U("ax.a", (1000,)), U("ax.b", (1000,))
+    z = native.axpby(dev(a), dev(b), 0.25, 3.0).cpu().numpy()
+    assert np.allclose(z, 0.25 * a + 3.0 * b, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,121 @@
+"""Whole-path parity on a real MI355X through the reference's module API (Unit2Mel /
+GaussianDiffusion / UNet1DConditionModel / Vocoder) against the committed golden fixtures
+(outputs of the reference's own leaf modules) and the numpy oracle.
+
+Stated tolerances (fp32 pipeline): UNet forward <= 2e-5 * absmax;
+full sampler and vocoder <= 1e-4 * absmax (the reference's own fp32-vs-fp64 drift over a
+50-step run is ~1e-6 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def unit2mel_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from diffusion.unit2mel import Unit2Mel
+    m = Unit2Mel(1280, 323, 80)
+    m.to("cuda").eval()
+    return m
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_unet_forward_vs_reference(golden, unit2mel_gpu, case):
+    g = golden("unet_fwd.npz")
+    unet = unit2mel_gpu.decoder.denoise_fn
+    t = g[f"{case}_t"]
+    tt = dev(t) if t.dtype != np.int64 else torch.from_numpy(t).cuda()
+    y = unet(dev(g[f"{case}_x"]), tt).sample.cpu().numpy()
+    assert y.shape == g[f"{case}_y"].shape
+    assert np.isfinite(y).all()
+    assert relmax(y, g[f"{case}_y"]) < 2e-5, relmax(y, g[f"{case}_y"])
+
+
+@pytest.mark.parametrize("name,method,speedup,k_step,B", [
+    ("dpm50", "dpm-solver", 20, 1000, 2), ("unipc20", "unipc", 50, 1000, 2),
+    ("ddim10", "ddim", 100, 1000, 2), ("pndm10", "pndm", 100, 1000, 1), ("ddpm12", None, 1, 12, 2)])
+def test_sampler_vs_reference(golden, unit2mel_gpu, monkeypatch, name, method, speedup, k_step, B):
+    """GaussianDiffusion.forward with the sampler RNG draws replaced by the recorded reference draws."""
+    g = golden("sampler.npz")
+    gd = unit2mel_gpu.decoder
+    noise = g[name + "_noise"]                  # [n_draws, B, 1, M, T] in the reference's draw order
+    draws = [dev(n) for n in noise]
+    real = torch.randn
+
+    def fake_randn(*a, **k):
+        return draws.pop(0) if draws else real(*a, **k)
+    monkeypatch.setattr(torch, "randn", fake_randn)
+    gd.k_step = k_step
+    try:
+        y = gd(dev(g["cond"][:B]), infer=True, infer_speedup=speedup, method=method).cpu().numpy()
+    finally:
+        gd.k_step = 1000
+    assert not draws
+    assert y.shape == g[name + "_y"].shape
+    assert relmax(y, g[name + "_y"]) < 1e-4, relmax(y, g[name + "_y"])
+
+
+def test_pndm_batch_gt1_raises_like_reference(unit2mel_gpu):
+    gd = unit2mel_gpu.decoder
+    with pytest.raises(RuntimeError):
+        gd(torch.zeros(2, 16, 256, device="cuda"), infer=True, infer_speedup=100, method="pndm")
+    with pytest.raises(NotImplementedError):
+        gd(torch.zeros(1, 16, 256, device="cuda"), infer=True, infer_speedup=100, method="bogus")
+
+
+def test_vocoder_vs_reference(golden):
+    from diffusion.vocoder import Vocoder
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights
+    g = golden("vocoder.npz")
+    h = arch.SYNTHETIC_VOCODER_H
+    state = init_weights.init_state(arch.generator_param_shapes(h), 0)
+    voc = Vocoder.__new__(Vocoder)
+    voc.vocoder = Hifi_VAEGAN(None, device="cuda", h=h, state=state)
+    wav = voc.infer(dev(g["z"])).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    assert relmax(wav, g["wav"]) < 1e-4, relmax(wav, g["wav"])
+
+
+def test_unit2mel_end_to_end_vs_oracle(unit2mel_gpu, monkeypatch):
+    """units -> cond -> 20-step UniPC -> mel through Unit2Mel.forward vs the oracle pipeline."""
+    from lds import arch, init_weights
+    from oracle import schedule, unit2mel as o_u2m
+    m = unit2mel_gpu
+    B, T = 2, 24
+    units = init_weights.uniform("e2e.units", (B, T, 1280), 21, -1.7, 1.7)
+    spk = np.array([[3], [322]], dtype=np.int64)
+    xT = init_weights.uniform("e2e.xT", (B, 1, 80, T), 21, -1.7, 1.7)
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: dev(xT))
+    y = m(dev(units), None, spk_id=torch.from_numpy(spk).cuda(), infer=True, infer_speedup=50, method="unipc").cpu().numpy()
+    w = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    cfg = arch.unet_config()
+    ref = o_u2m.unit2mel(w, cfg, arch.unet_blocks(cfg), schedule.diffusion_buffers(), units, spk, xT[:, 0], "unipc", 50)
+    assert y.shape == (B, T, 80)
+    assert relmax(y, ref) < 1e-4, relmax(y, ref)
+
+
+def test_batch_shard_invariance_full_size(unit2mel_gpu):
+    """BASELINE config sizes (T=512): an utterance's eps is bit-identical whether it is evaluated
+    alone or inside a batch of 4 (kernels never reduce across the batch axis), which is what makes
+    the multi-GPU batch split exact."""
+    from lds import init_weights
+    unet = unit2mel_gpu.decoder.denoise_fn
+    B, T = 4, 512
+    x = dev(init_weights.uniform("inv.x", (B, 336, T), 31, -2, 2))
+    t = dev(np.full((B,), 499.5, dtype=np.float32))
+    full = unet(x, t).sample
+    one = unet(x[2:3].contiguous(), t[2:3].contiguous()).sample
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[2:3], one)
