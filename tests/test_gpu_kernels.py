@@ -2,7 +2,7 @@
 (itself pinned to the reference's leaf modules by test_oracle_vs_golden.py).  All calls go
 through the C ABI (ctypes).  Tolerances: the kernels compute in exact fp32 (v_mfma_f32_32x32x2
 is a k-ordered fmaf chain), so differences against the oracle are summation-order only."""
-import ctypes as C
+import ctypes as ct
 
 import numpy as np
 import pytest
@@ -63,7 +63,7 @@ def run_conv(x1, w, bias=None, x2=None, stride=1, pad=0, dil=1, ups=0, norm=0, g
     a.res = dres.data_ptr() if dres is not None else None
     a.epilogue, a.tile = epi, tile
     out = torch.full((B, Cout, To), float("nan"), dtype=torch.float32, device="cuda")
-    native.check(L.lds_test_conv(C.byref(a), C.c_void_p(out.data_ptr()), B, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    native.check(L.lds_test_conv(ct.byref(a), ct.c_void_p(out.data_ptr()), B, ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -169,9 +169,8 @@ def test_attention(C, T, B):
     qkv = U(f"att{C}.{T}", (B, 3 * C, T), -1.5, 1.5)
     out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
     dq = dev(qkv)
-    native.check(native.lib().lds_test_attention(C.c_void_p(dq.data_ptr()) if False else __import__("ctypes").c_void_p(dq.data_ptr()),
-                                                 __import__("ctypes").c_void_p(out.data_ptr()), B, C, T, heads,
-                                                 __import__("ctypes").c_void_p(torch.cuda.current_stream().cuda_stream)))
+    native.check(native.lib().lds_test_attention(ct.c_void_p(dq.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, heads,
+                                                 ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     q, k, v = [qkv[:, i * C:(i + 1) * C].reshape(B, heads, d, T).astype(np.float64) for i in range(3)]
     s = np.einsum("bhdq,bhdk->bhqk", q, k) / np.sqrt(d)
