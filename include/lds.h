@@ -131,6 +131,13 @@ int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out)
 int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes,
                         int B, int T, void* stream);
 
+/* ---- per-launch HIP-event timing for bench.py's roofline leg (off by default) ------------------
+ * lds_prof_enable(1) clears and starts recording one event pair per kernel launch on the launch
+ * stream; lds_prof_summary synchronises them and writes a JSON list of
+ * {name,count,ms,flops,bytes} aggregates (algorithmic flops/bytes per kernel family). */
+int lds_prof_enable(int on);
+int lds_prof_summary(char* buf, size_t cap);
+
 /* ---- single-op entry points (used by the parity tests to check each kernel alone) ----------- */
 typedef struct {
     const float* x1; const float* x2;   /* dev inputs [B,C1,Tsrc], [B,C2,Tsrc] (x2 may be NULL)  */

@@ -102,4 +102,15 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, int idx_of
                               int nrows, hipStream_t s);
 hipError_t launch_resample_nearest(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
 
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+    bool on;
+    hipStream_t s;
+    ProfScope(hipStream_t st, const char* name, double flops, double bytes);
+    ~ProfScope();
+};
+
 }  // namespace lds

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) small_linear_kernel(const float* __restri
 hipError_t launch_small_linear(const float* W, const float* bias, const float* in, int in_stride, int in_mode,
                                const float* freqs, float* out, int out_stride, int M, int K, int B, hipStream_t s) {
     if (K % 4) return hipErrorInvalidValue;
+    ProfScope ps(s, "small_linear", 2.0 * M * (double)K * B, 4.0 * M * (double)K);
     hipLaunchKernelGGL(small_linear_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, s, W, bias, in, in_stride, in_mode, freqs, out,
                        out_stride, M, K, B);
     return hipGetLastError();
@@ -102,6 +103,7 @@ hipError_t launch_ew(int op, float* out, const float* a, const float* b, const f
                      float c2, float c3, float c4, long long n, hipStream_t s) {
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    ProfScope ps(s, "ew", 0.0, 4.0 * 3.0 * (double)n);
     hipLaunchKernelGGL(ew_kernel, dim3((unsigned)blocks), dim3(256), 0, s, op, out, a, b, c, d, c0, c1, c2, c3, c4, n);
     return hipGetLastError();
 }

@@ -41,6 +41,58 @@ extern "C" int lds_version(void) { return 1; }
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
+// event profiler (off by default; bench.py turns it on for one instrumented pass)
+// ------------------------------------------------------------------------------------------------
+struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+lds::ProfScope::ProfScope(hipStream_t st, const char* name, double flops, double bytes) : on(g_prof_on), s(st) {
+    if (!on) return;
+    ProfRec r;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+}
+lds::ProfScope::~ProfScope() {
+    if (on) (void)hipEventRecord(g_prof.back().b, s);
+}
+
+extern "C" int lds_prof_enable(int on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return LDS_OK;
+}
+
+// JSON: [{"name":..., "count":n, "ms":total, "flops":total, "bytes":total}, ...]; synchronises the recorded events.
+extern "C" int lds_prof_summary(char* buf, size_t cap) {
+    struct Agg { long long n = 0; double ms = 0, fl = 0, by = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+            return fail(LDS_EHIP, "profiler event read failed");
+        Agg& a = agg[r.name];
+        a.n++; a.ms += ms; a.fl += r.flops; a.by += r.bytes;
+    }
+    std::string out = "[";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[512];
+        snprintf(line, sizeof(line), "%s{\"name\":\"%s\",\"count\":%lld,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}", first ? "" : ",",
+                 kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.fl, kv.second.by);
+        out += line;
+        first = false;
+    }
+    out += "]";
+    if (out.size() + 1 > cap) return fail(LDS_ENOMEM, "profile summary needs %zu bytes", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return LDS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // device allocations owned by a handle
 // ------------------------------------------------------------------------------------------------
 struct Owner {
@@ -184,7 +236,20 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.phases = o.phases; a.tpad = o.tpad;
     a.Cout = o.Cout > 0 ? o.Cout : (o.epi == EPI_GEGLU ? W.Co / 2 : W.Co / o.phases);
     a.B = B;
-    hipError_t e = launch_conv_gemm(a, o.tile, st);
+    const double real_rows = (o.epi == EPI_GEGLU || o.phases > 1) ? (double)W.Co : (double)(a.Cout);
+    const double flops = 2.0 * B * (double)a.To * real_rows * (double)W.Ci * (double)W.K;
+    const double bytes = 4.0 * ((double)B * W.Ci * s.Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.Tout * (o.res ? 2.0 : 1.0));
+    hipError_t e;
+    {
+        ProfScope ps(st, "conv_gemm", flops, bytes);
+        e = launch_conv_gemm(a, o.tile, st);
+    }
+    if (g_prof_on && !g_prof.empty() && g_prof.back().name == "conv_gemm") {
+        const char* c = conv_gemm_last_config();   // "BM.. BN.. KT.. S.. U.. grid ..."
+        std::string cfgs(c);
+        size_t p = cfgs.find(" grid");
+        g_prof.back().name = "conv_gemm<" + cfgs.substr(0, p) + ">";
+    }
     if (e != hipSuccess)
         return fail(LDS_EHIP, "conv_gemm launch failed (%s): Co %d Ci %d K %d stride %d dil %d ups %d To %d", hipGetErrorString(e), W.Co,
                     W.Ci, W.K, o.stride, o.dil, o.ups, a.To);
@@ -539,7 +604,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         ConvOpt oq;
         oq.norm_mode = NORM_COLSTAT; oq.cmean = w.lmean; oq.crstd = w.lrstd; oq.gamma = t.ln_g[a]; oq.beta = t.ln_b[a];
         LDS_TRY(run_conv(t.qkv[a], sh, oq, w.qkv, B, st));
-        HIP_TRY(launch_attention(w.qkv, w.att, B, C, T, u->heads, st));
+        { ProfScope ps(st, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T); HIP_TRY(launch_attention(w.qkv, w.att, B, C, T, u->heads, st)); }
         Src sa{w.att, C, nullptr, 0, T};
         ConvOpt oo;
         oo.res = h;

@@ -86,6 +86,7 @@ hipError_t launch_gn_coef(const float* x1, const float* x2, int C1, int C2, int 
                           float eps, const float* gamma, const float* beta, const float* ss, int ss_stride, int ss_off,
                           float4* coef, int B, hipStream_t s) {
     if ((C1 + C2) % groups != 0) return hipErrorInvalidValue;
+    ProfScope ps(s, "gn_coef", 0.0, 4.0 * 2.0 * B * (double)(C1 + C2) * T);
     hipLaunchKernelGGL(gn_coef_kernel<512>, dim3(groups, B), dim3(512), 0, s, x1, x2, C1, C2, T, xb1, xb2, groups, eps, gamma,
                        beta, ss, ss_stride, ss_off, coef);
     return hipGetLastError();
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(256) ln_stats_kernel(const float* __restrict__
 }
 
 hipError_t launch_ln_stats(const float* x, int C, int T, float eps, float* mean, float* rstd, int B, hipStream_t s) {
+    ProfScope ps(s, "ln_stats", 0.0, 4.0 * 2.0 * B * (double)C * T);
     hipLaunchKernelGGL(ln_stats_kernel, dim3((T + 31) / 32, B), dim3(256), 0, s, x, C, T, eps, mean, rstd);
     return hipGetLastError();
 }

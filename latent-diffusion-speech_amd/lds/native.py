@@ -39,7 +39,7 @@ EXPORTS = [
     "lds_last_error", "lds_version", "lds_unet_create", "lds_unet_destroy", "lds_unet_workspace_bytes",
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
-    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_test_conv", "lds_test_attention",
+    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_attention",
     "lds_test_conv_transpose"]
 
 
@@ -194,6 +194,18 @@ class Embed:
         check(lib().lds_embed_forward(self.h, _dev(units, torch.float32), _dev(sid) if sid is not None else None,
                                       _dev(cond), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
         return cond
+
+
+def prof_enable(on=True):
+    check(lib().lds_prof_enable(1 if on else 0))
+
+
+def prof_summary():
+    """list of dicts {name,count,ms,flops,bytes}; synchronises the recorded events."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().lds_prof_summary(buf, C.c_size_t(len(buf))))
+    return json.loads(buf.value.decode())
 
 
 def axpby(a, b, c0, c1):
