@@ -8,13 +8,19 @@
 // (co contiguous) so that BOTH MFMA operands are "k-major, unit stride along the lane axis":
 //   A (weights)     lane l reads Ws[k0 + (l>>5)][m0 + (l&31)]
 //   B (activations) lane l reads Xs[k0 + (l>>5)][window(n0 + (l&31), tap)]
-// i.e. conflict-free ds_read_b32 and fully coalesced 16-byte global loads along the frame axis.
+// i.e. conflict-free ds_read_b32 and coalesced 16-byte global loads along the frame axis.
 // The activation window (BN*stride + halo frames of BK channels) is staged in LDS once per
 // K-step and re-read at shifted offsets by every tap (the "LDS-staged 1-D convolution window").
-// While staging, the producer's normalisation is applied on the fly (GroupNorm/LayerNorm
-// statistics come from small side kernels), optionally followed by SiLU / LeakyReLU, so
+// While staging, the producer's normalisation is applied on the fly (GroupNorm coefficients come
+// from a small side kernel; LayerNorm statistics are combined from per-32-channel partials that
+// the producing conv_gemm emitted in its epilogue), optionally followed by SiLU / LeakyReLU, so
 // normalised tensors are never materialised in HBM.  A second source pointer implements the
 // UNet's skip-concat on read; `ups` reads a 2x nearest-upsampled view of the source.
+//
+// Pipeline: LDS is double buffered, one barrier per K-step.  Global loads for tile k+2 are issued
+// in the middle of tile k's MFMAs; the transform + LDS writes of tile k+1 are interleaved with the
+// first half of tile k's MFMAs (an fp32 MFMA occupies the matrix pipe for 64 cycles and leaves the
+// wave free to issue VALU / DS work), so at one wave per SIMD the matrix pipe stays busy.
 #include "kernels.h"
 
 #include <math.h>
@@ -24,257 +30,353 @@ namespace lds {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+static __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + expf(-v)); }
 
 static __device__ __forceinline__ int floor4(int s) { return (s >= 0) ? (s & ~3) : -(((-s) + 3) & ~3); }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
 struct ConvCfg {
-    static constexpr int BK = 16;
     static constexpr int WAVES_M = (BM >= 64) ? 2 : 1;
     static constexpr int WAVES_N = 4 / WAVES_M;
     static constexpr int TM = BM / (32 * WAVES_M);
     static constexpr int TN = BN / (32 * WAVES_N);
+    static constexpr int TPR = 256 / BK;   // threads that stage one activation row
     static constexpr int XWMAX = UPS ? (BN / 2 + 2 + 3) : ((BN - 1) * STRIDE + (KT - 1) * DILMAX + 1 + 3);
     static constexpr int XW4MAX = (XWMAX + 3) / 4;
-    static constexpr int XCH = (BK * XW4MAX + 255) / 256;
+    static constexpr int XCH = (XW4MAX + TPR - 1) / TPR;
     static constexpr int WCHUNKS = KT * BK * BM / 4;
     static constexpr int WCH = (WCHUNKS + 255) / 256;
-    static constexpr size_t lds_bytes(int xw4) { return (size_t)(KT * BK * BM + BK * xw4 * 4) * sizeof(float); }
+    static constexpr int G = KT * BK / 2;          // MFMA groups (one k-pair of one tap) per K-step
+    static constexpr bool INTERLEAVE = (KT <= 3);  // fully unrolled K-step with commit pieces between MFMAs
+    static constexpr size_t lds_bytes(int xw4) { return (size_t)(2 * (KT * BK * BM + BK * xw4 * 4) + 2 * xw4 * 4) * sizeof(float); }
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX>
-__global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs p) {
-    using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX>;
-    constexpr int BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ws = smem;                    // [KT][BK][BM]
-    float* Xs = smem + KT * BK * BM;     // [BK][xwp]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+// All per-thread state lives in one struct whose methods are force-inlined: every register array is a
+// member indexed by compile-time constants (template recursion), so nothing falls back to scratch.
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
+struct ConvKernel {
+    using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
+    static constexpr int TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH, TPR = Cfg::TPR, G = Cfg::G;
+    static constexpr int P = XCH + WCH;      // commit pieces per K-step
+    static constexpr int HALF = G / 2;
 
-    const int nMb = p.Mp / BM;
-    const int mb = blockIdx.x % nMb;          // M fastest: blocks that share an activation tile are neighbours
-    const int nb = blockIdx.x / nMb;
-    const int b = blockIdx.y;
-    const int m0 = mb * BM, t0 = nb * BN;
+    const ConvArgs& p;
+    float* smem;
+    int tid, c, h, wm, wn, b, m0, t0;
+    int s_al, off, xw4, xwp, stage;
+    float* cst;
+    bool vec_ok;
+    int xrow, xc0, arow;
+    int bcol[TN];
+    f32x4 xr[XCH];
+    f32x4 wr[WCH];
+    float cf0, cf1, cf2;               // ROWCOEF: mu, a, b ; COLSTAT: gamma, beta
+    f32x16 acc[TM][TN];
 
-    // ---- activation window geometry ----
-    int s0, s_al, off, width;
-    if (UPS) {
-        s0 = (t0 - 1) >> 1;
-        s_al = floor4(s0);
-        off = 0;
-        width = ((t0 + BN) >> 1) - s_al + 1;
-    } else {
-        s0 = t0 * STRIDE - p.pad;
-        s_al = floor4(s0);
-        off = s0 - s_al;
-        width = (BN - 1) * STRIDE + (KT - 1) * p.dil + 1 + off;
+    __device__ __forceinline__ ConvKernel(const ConvArgs& p_, float* smem_) : p(p_), smem(smem_) {}
+
+    __device__ __forceinline__ void setup() {
+        tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        c = lane & 31; h = lane >> 5;
+        wm = wave / Cfg::WAVES_N; wn = wave % Cfg::WAVES_N;
+        const int nMb = p.Mp / BM;
+        const int mb = blockIdx.x % nMb;          // M fastest: blocks that share an activation tile are neighbours
+        const int nb = blockIdx.x / nMb;
+        b = blockIdx.y;
+        m0 = mb * BM; t0 = nb * BN;
+        int width;
+        if (UPS) {
+            s_al = floor4((t0 - 1) >> 1);
+            off = 0;
+            width = ((t0 + BN) >> 1) - s_al + 1;
+        } else {
+            const int s0 = t0 * STRIDE - p.pad;
+            s_al = floor4(s0);
+            off = s0 - s_al;
+            width = (BN - 1) * STRIDE + (KT - 1) * p.dil + 1 + off;
+        }
+        xw4 = (width + 3) >> 2;
+        xwp = xw4 * 4;
+        stage = KT * BK * BM + BK * xwp;   // floats per LDS stage
+        cst = smem + 2 * stage;            // [2][xwp] LayerNorm mean / rstd of the window's frames
+        vec_ok = ((p.Tsrc & 3) == 0);
+        xrow = tid / TPR;                  // one activation row per thread, chunks xc0, xc0+TPR, ...
+        xc0 = tid - xrow * TPR;
+        arow = wm * TM * 32 + c;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * TN * 32 + j * 32 + c;
+            bcol[j] = UPS ? nl : (off + nl * STRIDE);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        cf0 = 0.f; cf1 = 1.f; cf2 = 0.f;
     }
-    const int xw4 = (width + 3) >> 2;
-    const int xwp = xw4 * 4;
-    const bool vec_ok = ((p.Tsrc & 3) == 0);
 
-    // per-thread staging assignments (loop invariant)
-    int xrow[XCH], xcol[XCH];
-    bool xval[XCH];
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-        int q = tid + i * 256;
-        xval[i] = q < BK * xw4;
-        xrow[i] = q / xw4;
-        xcol[i] = (q - xrow[i] * xw4) * 4;
-    }
-    float4 cm4[XCH], cr4[XCH];
-    if (p.norm_mode == NORM_COLSTAT) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            float m_[4], r_[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int s = s_al + xcol[i] + e;
-                bool ok = xval[i] && s >= 0 && s < p.Tsrc;
-                m_[e] = ok ? p.cmean[(long long)b * p.Tsrc + s] : 0.f;
-                r_[e] = ok ? p.crstd[(long long)b * p.Tsrc + s] : 0.f;
+    // LayerNorm over channels (reference attention.py:83,102,118): per-frame mean / rstd for this window
+    __device__ __forceinline__ void colstat_prologue() {
+        for (int j = tid; j < xwp; j += 256) {
+            const int s = s_al + j;
+            float mean = 0.f, rstd = 0.f;
+            if (s >= 0 && s < p.Tsrc) {
+                if (p.lnpart) {
+                    // Chan combination of per-32-channel (mean, M2) partials written by the producer's epilogue
+                    float n = 0.f, m2 = 0.f;
+                    for (int q = 0; q < p.ln_np; ++q) {
+                        const float2 pr = p.lnpart[((long long)b * p.ln_np + q) * p.Tsrc + s];
+                        const float d = pr.x - mean;
+                        const float nn = n + 32.f;
+                        mean += d * (32.f / nn);
+                        m2 += pr.y + d * d * (n * 32.f / nn);
+                        n = nn;
+                    }
+                    rstd = 1.0f / sqrtf(m2 / n + p.ln_eps);
+                } else {
+                    mean = p.cmean[(long long)b * p.Tsrc + s];
+                    rstd = p.crstd[(long long)b * p.Tsrc + s];
+                }
             }
-            cm4[i] = make_float4(m_[0], m_[1], m_[2], m_[3]);
-            cr4[i] = make_float4(r_[0], r_[1], r_[2], r_[3]);
+            cst[j] = mean;
+            cst[xwp + j] = rstd;
         }
     }
 
-    float4 xr[XCH], xc[XCH], wr[WCH];
-
-    auto fetch = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xc[i] = make_float4(0.f, 1.f, 0.f, 0.f);
-            if (xval[i]) {
-                const int ci = kc * BK + xrow[i];
-                const float* src = (ci < p.C1) ? (p.x1 + (long long)b * p.xb1 + (long long)ci * p.Tsrc)
-                                               : (p.x2 + (long long)b * p.xb2 + (long long)(ci - p.C1) * p.Tsrc);
-                const int s = s_al + xcol[i];
+    template <int I>
+    __device__ __forceinline__ void fetch_x(const float* src) {
+        if constexpr (I < XCH) {
+            const int c4 = xc0 + I * TPR;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c4 < xw4) {
+                const int s = s_al + c4 * 4;
                 if (vec_ok && s >= 0 && s + 3 < p.Tsrc) {
-                    xr[i] = *reinterpret_cast<const float4*>(src + s);
+                    v = *reinterpret_cast<const f32x4*>(src + s);
                 } else {
-                    float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < p.Tsrc) ? src[s + e] : 0.f;
-                    xr[i] = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                if (p.norm_mode == NORM_ROWCOEF) xc[i] = p.coef[(long long)b * p.Ci + ci];
-                else if (p.norm_mode == NORM_COLSTAT) { xc[i].x = p.gamma[ci]; xc[i].y = p.beta[ci]; }
             }
+            xr[I] = v;
+            fetch_x<I + 1>(src);
         }
-#pragma unroll
-        for (int j = 0; j < WCH; ++j) {
-            const int q = tid + j * 256;
+    }
+    template <int J>
+    __device__ __forceinline__ void fetch_w(int kc) {
+        if constexpr (J < WCH) {
+            const int q = tid + J * 256;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < Cfg::WCHUNKS) {
                 const int tap = q / (BK * BM / 4);
                 const int rem = q - tap * (BK * BM / 4);
                 const int k = rem / (BM / 4), m4 = rem - k * (BM / 4);
-                wr[j] = *reinterpret_cast<const float4*>(p.w + ((long long)(tap * p.Ci + kc * BK + k)) * p.Mp + m0 + 4 * m4);
+                v = *reinterpret_cast<const f32x4*>(p.w + ((long long)(tap * p.Ci + kc * BK + k)) * p.Mp + m0 + 4 * m4);
             }
+            wr[J] = v;
+            fetch_w<J + 1>(kc);
         }
-    };
-
-    auto xform = [&](float v, float mu, float a, float bb, bool in) -> float {
-        if (!in) return 0.f;
-        if (p.norm_mode != NORM_NONE) v = (v - mu) * a + bb;
-        if (p.act_in == ACT_SILU) v = silu_f(v);
-        else if (p.act_in == ACT_LRELU) v = (v >= 0.f) ? v : v * p.slope;
-        return v;
-    };
-
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            if (xval[i]) {
-                const int s = s_al + xcol[i];
-                float4 v = xr[i];
-                if (p.norm_mode == NORM_COLSTAT) {
-                    const float g = xc[i].x, be = xc[i].y;
-                    v.x = xform(v.x, cm4[i].x, cr4[i].x * g, be, s + 0 >= 0 && s + 0 < p.Tsrc);
-                    v.y = xform(v.y, cm4[i].y, cr4[i].y * g, be, s + 1 >= 0 && s + 1 < p.Tsrc);
-                    v.z = xform(v.z, cm4[i].z, cr4[i].z * g, be, s + 2 >= 0 && s + 2 < p.Tsrc);
-                    v.w = xform(v.w, cm4[i].w, cr4[i].w * g, be, s + 3 >= 0 && s + 3 < p.Tsrc);
-                } else {
-                    const float mu = xc[i].x, a = xc[i].y, bb = xc[i].z;
-                    v.x = xform(v.x, mu, a, bb, s + 0 >= 0 && s + 0 < p.Tsrc);
-                    v.y = xform(v.y, mu, a, bb, s + 1 >= 0 && s + 1 < p.Tsrc);
-                    v.z = xform(v.z, mu, a, bb, s + 2 >= 0 && s + 2 < p.Tsrc);
-                    v.w = xform(v.w, mu, a, bb, s + 3 >= 0 && s + 3 < p.Tsrc);
-                }
-                *reinterpret_cast<float4*>(Xs + xrow[i] * xwp + xcol[i]) = v;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WCH; ++j) {
-            const int q = tid + j * 256;
-            if (q < Cfg::WCHUNKS) *reinterpret_cast<float4*>(Ws + 4 * q) = wr[j];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // B-operand column of this lane for tile j at tap 0
-    int bcol[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nl = wn * TN * 32 + j * 32 + c;
-        bcol[j] = UPS ? nl : (off + nl * STRIDE);
     }
-    const int arow = wm * TM * 32 + c;
-
-    const int nk = p.Ci / BK;
-    fetch(0);
-    commit();
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) fetch(kc + 1);
-#pragma unroll 1
-        for (int tap = 0; tap < KT; ++tap) {
-            const float* wt = Ws + tap * BK * BM + arow;
-            int col[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) col[j] = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - s_al) : (bcol[j] + tap * p.dil);
-#pragma unroll
-            for (int k2 = 0; k2 < BK / 2; ++k2) {
-                const int k = 2 * k2 + h;
-                float a[TM], bv[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = wt[k * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = Xs[k * xwp + col[j]];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
-            }
+    __device__ __forceinline__ void fetch(int kc) {
+        const int ci = kc * BK + xrow;
+        const float* src = (ci < p.C1) ? (p.x1 + (long long)b * p.xb1 + (long long)ci * p.Tsrc)
+                                       : (p.x2 + (long long)b * p.xb2 + (long long)(ci - p.C1) * p.Tsrc);
+        fetch_x<0>(src);
+        float a0 = 0.f, a1 = 1.f, a2 = 0.f;
+        if (p.norm_mode == NORM_ROWCOEF) {
+            const float4 cf = p.coef[(long long)b * p.Ci + ci];
+            a0 = cf.x; a1 = cf.y; a2 = cf.z;
+        } else if (p.norm_mode == NORM_COLSTAT) {
+            a0 = p.gamma[ci]; a1 = p.beta[ci];
         }
+        cf0 = a0; cf1 = a1; cf2 = a2;
+        fetch_w<0>(kc);
+    }
+
+    __device__ __forceinline__ float act(float v) const {
+        if (p.act_in == ACT_SILU) return silu_f(v);
+        if (p.act_in == ACT_LRELU) return (v >= 0.f) ? v : v * p.slope;
+        return v;
+    }
+
+    // piece PC of the staged tile: PC < XCH -> activation chunk (transform + ds_write), else weight chunk
+    template <int PC>
+    __device__ __forceinline__ void commit_piece(float* st) {
+        if constexpr (PC < XCH) {
+            const int c4 = xc0 + PC * TPR;
+            if (c4 < xw4) {
+                const int s = s_al + c4 * 4;
+                f32x4 v = xr[PC];
+                if (p.norm_mode == NORM_COLSTAT) {
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(cst + c4 * 4);
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(cst + xwp + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * (rs[e] * cf0) + cf1;
+                } else if (p.norm_mode == NORM_ROWCOEF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] - cf0) * cf1 + cf2;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < p.Tsrc) ? act(v[e]) : 0.f;
+                *reinterpret_cast<f32x4*>(st + KT * BK * BM + xrow * xwp + c4 * 4) = v;
+            }
+        } else {
+            constexpr int J = PC - XCH;
+            const int q = tid + J * 256;
+            if (q < Cfg::WCHUNKS) *reinterpret_cast<f32x4*>(st + 4 * q) = wr[J];
+        }
+    }
+    template <int LO, int HI>
+    __device__ __forceinline__ void commit_range(float* st) {
+        if constexpr (LO < HI) {
+            commit_piece<LO>(st);
+            commit_range<LO + 1, HI>(st);
+        }
+    }
+
+    __device__ __forceinline__ void mfma_group(const float* st, int tap, int k2) {
+        const float* wt = st + tap * BK * BM + arow;
+        const float* xs = st + KT * BK * BM;
+        const int k = 2 * k2 + h;
+        float a[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = wt[k * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - s_al) : (bcol[j] + tap * p.dil);
+            bv[j] = xs[k * xwp + col];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+
+    // one K-step, fully unrolled: the first half of the MFMA groups carries the commit pieces of tile kc+1,
+    // the fetch of tile kc+2 is issued at the midpoint (its registers are free by then)
+    template <int g>
+    __device__ __forceinline__ void kstep(const float* cur, float* nxt, bool do_commit, bool do_fetch, int kc) {
+        if constexpr (g < G) {
+            if constexpr (g < HALF) {
+                constexpr int p_lo = (g * P) / HALF, p_hi = ((g + 1) * P) / HALF;
+                if (do_commit) commit_range<p_lo, p_hi>(nxt);
+            }
+            if constexpr (g == HALF) {
+                if (do_fetch) fetch(kc + 2);
+            }
+            mfma_group(cur, g / (BK / 2), g % (BK / 2));
+            kstep<g + 1>(cur, nxt, do_commit, do_fetch, kc);
+        }
+    }
+
+    __device__ __forceinline__ void mainloop() {
+        const int nk = p.Ci / BK;
+        fetch(0);
+        commit_range<0, P>(smem);
+        if (nk > 1) fetch(1);
         __syncthreads();
-        if (kc + 1 < nk) {
-            commit();
+        for (int kc = 0; kc < nk; ++kc) {
+            const float* cur = smem + (kc & 1) * stage;
+            float* nxt = smem + ((kc & 1) ^ 1) * stage;
+            const bool do_commit = kc + 1 < nk, do_fetch = kc + 2 < nk;
+            if constexpr (Cfg::INTERLEAVE) {
+                kstep<0>(cur, nxt, do_commit, do_fetch, kc);
+            } else {
+                if (do_commit) commit_range<0, P>(nxt);
+                if (do_fetch) fetch(kc + 2);
+#pragma unroll 1
+                for (int tap = 0; tap < KT; ++tap) {
+#pragma unroll
+                    for (int k2 = 0; k2 < BK / 2; ++k2) mfma_group(cur, tap, k2);
+                }
+            }
             __syncthreads();
         }
     }
 
-    // ---- epilogue ----
-    const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
+    __device__ __forceinline__ void epilogue() {
+        const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        if (geglu && i == 1) break;
+        for (int i = 0; i < TM; ++i) {
+            if (geglu && i == 1) break;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = t0 + wn * TN * 32 + j * 32 + c;
+            for (int j = 0; j < TN; ++j) {
+                const int n = t0 + wn * TN * 32 + j * 32 + c;
+                float vals[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = m0 + wm * TM * 32 + i * 32 + rloc;      // packed row
-                float v = acc[i][j][r];
-                int orow;
-                if (geglu) {
-                    float g = acc[TM - 1][j][r];
-                    if (p.bias) { v += p.bias[m]; g += p.bias[m + 32]; }
-                    v = v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
-                    orow = (m0 + wm * 64) / 2 + rloc;
-                } else {
-                    if (p.bias) v += p.bias[m];
-                    orow = m;
+                for (int r = 0; r < 16; ++r) {
+                    const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int m = m0 + wm * TM * 32 + i * 32 + rloc;      // packed row
+                    float v = acc[i][j][r];
+                    int orow;
+                    if (geglu) {
+                        float g = acc[TM - 1][j][r];
+                        if (p.bias) { v += p.bias[m]; g += p.bias[m + 32]; }
+                        v = v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+                        orow = (m0 + wm * 64) / 2 + rloc;
+                    } else {
+                        if (p.bias) v += p.bias[m];
+                        orow = m;
+                    }
+                    int co = orow, to = n;
+                    if (p.phases > 1) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
+                    if (co < p.Cout && n < p.To && to >= 0 && to < p.Tout) {
+                        if (p.bias_bc) v += p.bias_bc[(long long)b * p.Cout + co];
+                        const long long oi = ((long long)b * p.Cout + co) * p.Tout + to;
+                        if (p.res) v += p.res[oi];
+                        if (p.epi == EPI_TANH) v = tanhf(v);
+                        if (p.accum) v += p.out[oi];
+                        if (p.out_div != 1.0f) v = v / p.out_div;
+                        p.out[oi] = v;
+                    }
+                    vals[r] = v;
                 }
-                int co = orow, to = n;
-                if (p.phases > 1) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
-                if (co < p.Cout && n < p.To && to >= 0 && to < p.Tout) {
-                    if (p.bias_bc) v += p.bias_bc[(long long)b * p.Cout + co];
-                    const long long oi = ((long long)b * p.Cout + co) * p.Tout + to;
-                    if (p.res) v += p.res[oi];
-                    if (p.epi == EPI_TANH) v = tanhf(v);
-                    if (p.accum) v += p.out[oi];
-                    if (p.out_div != 1.0f) v = v / p.out_div;
-                    p.out[oi] = v;
+                if (p.lnpart_out) {
+                    // (mean, M2) of this frame over the 32 output channels of this MFMA tile: 16 values in this lane,
+                    // 16 in lane^32; combined with Chan's formula and consumed by the next layer's LayerNorm-on-load
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += vals[r];
+                    const float m16 = s * (1.0f / 16.0f);
+                    float q = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = vals[r] - m16; q += d * d; }
+                    const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(q, 32, 64);
+                    const float d = mo - m16;
+                    const float mean = 0.5f * (m16 + mo);
+                    const float m2 = (q + qo) + d * d * 8.0f;
+                    const int tile32 = (m0 + wm * TM * 32 + i * 32) >> 5;
+                    if (h == 0 && n < p.To && tile32 * 32 < p.Cout)
+                        p.lnpart_out[((long long)b * (p.Cout >> 5) + tile32) * p.Tout + n] = make_float2(mean, m2);
                 }
             }
         }
     }
+};
+
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ConvKernel<BM, BN, KT, STRIDE, UPS, DILMAX, BK> k(p, smem);
+    k.setup();
+    if (p.norm_mode == NORM_COLSTAT) {
+        k.colstat_prologue();
+        __syncthreads();   // cst visible before the first commit
+    }
+    k.mainloop();
+    k.epilogue();
 }
 
 static thread_local char g_cfg[96] = "";
 const char* conv_gemm_last_config() { return g_cfg; }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
-    using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX>;
+    using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
     int width;
     if (UPS) width = BN / 2 + 2 + 3;
     else width = (BN - 1) * STRIDE + (KT - 1) * a.dil + 1 + 3;
@@ -283,14 +385,14 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const size_t lds = Cfg::lds_bytes(xw4);
     const int nN = (a.To + BN - 1) / BN;
     dim3 grid((a.Mp / BM) * nN, a.B);
-    auto kern = conv_gemm_kernel<BM, BN, KT, STRIDE, UPS, DILMAX>;
+    auto kern = conv_gemm_kernel<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    snprintf(g_cfg, sizeof(g_cfg), "BM%d BN%d KT%d S%d U%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, grid.x, grid.y, lds);
+    snprintf(g_cfg, sizeof(g_cfg), "BM%d BN%d KT%d S%d U%d BK%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, grid.x, grid.y, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -313,10 +415,11 @@ static int auto_tile(const ConvArgs& a) {
     return (blocks(64, 128) >= 512) ? 64128 : 64064;   // vocoder taps 2/3(dilated)/7/11
 }
 
-#define LDS_CASE(BM, BN, KT, ST, UP, DM) return launch_cfg<BM, BN, KT, ST, UP, DM>(a, s)
+#define LDS_CASE(BM, BN, KT, ST, UP, DM, BK) return launch_cfg<BM, BN, KT, ST, UP, DM, BK>(a, s)
 
 hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
     if (a.Ci % 16 != 0 || a.C1 % 16 != 0 || a.Mp % 32 != 0 || a.B <= 0 || a.To <= 0) return hipErrorInvalidValue;
+    if (a.lnpart_out && (a.epi != EPI_NONE || a.phases != 1 || (a.Cout & 31))) return hipErrorInvalidValue;
     if (tile == 0) tile = auto_tile(a);
     const int bm = tile / 1000;
     if (a.Mp % bm != 0) return hipErrorInvalidValue;
@@ -324,38 +427,46 @@ hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const bool wide = a.dil > 1;
     if (a.dil > 5) return hipErrorInvalidValue;
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0);
+    const bool k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     switch (tile) {
         case 128128:
-            if (key == 110) LDS_CASE(128, 128, 1, 1, false, 1);
-            if (key == 310 && !wide) LDS_CASE(128, 128, 3, 1, false, 1);
+            if (key == 110 && k32) LDS_CASE(128, 128, 1, 1, false, 1, 32);
+            if (key == 110) LDS_CASE(128, 128, 1, 1, false, 1, 16);
+            if (key == 310 && !wide) LDS_CASE(128, 128, 3, 1, false, 1, 16);
             break;
         case 128064:
-            if (key == 110) LDS_CASE(128, 64, 1, 1, false, 1);
-            if (key == 310 && !wide) LDS_CASE(128, 64, 3, 1, false, 1);
+            if (key == 110 && k32) LDS_CASE(128, 64, 1, 1, false, 1, 32);
+            if (key == 110) LDS_CASE(128, 64, 1, 1, false, 1, 16);
+            if (key == 310 && !wide) LDS_CASE(128, 64, 3, 1, false, 1, 16);
             break;
         case 64064:
-            if (key == 110) LDS_CASE(64, 64, 1, 1, false, 1);
-            if (key == 210) LDS_CASE(64, 64, 2, 1, false, 1);
-            if (key == 310 && !wide) LDS_CASE(64, 64, 3, 1, false, 1);
-            if (key == 310 && wide) LDS_CASE(64, 64, 3, 1, false, 5);
-            if (key == 320) LDS_CASE(64, 64, 3, 2, false, 1);
-            if (key == 311) LDS_CASE(64, 64, 3, 1, true, 1);
-            if (key == 710) LDS_CASE(64, 64, 7, 1, false, 5);
-            if (key == 1110) LDS_CASE(64, 64, 11, 1, false, 5);
+            if (key == 110 && k64) LDS_CASE(64, 64, 1, 1, false, 1, 64);
+            if (key == 110) LDS_CASE(64, 64, 1, 1, false, 1, 16);
+            if (key == 210) LDS_CASE(64, 64, 2, 1, false, 1, 16);
+            if (key == 310 && !wide && k32) LDS_CASE(64, 64, 3, 1, false, 1, 32);
+            if (key == 310 && !wide) LDS_CASE(64, 64, 3, 1, false, 1, 16);
+            if (key == 310 && wide) LDS_CASE(64, 64, 3, 1, false, 5, 16);
+            if (key == 320 && k32) LDS_CASE(64, 64, 3, 2, false, 1, 32);
+            if (key == 320) LDS_CASE(64, 64, 3, 2, false, 1, 16);
+            if (key == 311 && k32) LDS_CASE(64, 64, 3, 1, true, 1, 32);
+            if (key == 311) LDS_CASE(64, 64, 3, 1, true, 1, 16);
+            if (key == 710) LDS_CASE(64, 64, 7, 1, false, 5, 16);
+            if (key == 1110) LDS_CASE(64, 64, 11, 1, false, 5, 16);
             break;
         case 64128:
-            if (key == 110) LDS_CASE(64, 128, 1, 1, false, 1);
-            if (key == 210) LDS_CASE(64, 128, 2, 1, false, 1);
-            if (key == 310) LDS_CASE(64, 128, 3, 1, false, 5);
-            if (key == 710) LDS_CASE(64, 128, 7, 1, false, 5);
-            if (key == 1110) LDS_CASE(64, 128, 11, 1, false, 5);
+            if (key == 110) LDS_CASE(64, 128, 1, 1, false, 1, 16);
+            if (key == 210) LDS_CASE(64, 128, 2, 1, false, 1, 16);
+            if (key == 310) LDS_CASE(64, 128, 3, 1, false, 5, 16);
+            if (key == 710) LDS_CASE(64, 128, 7, 1, false, 5, 16);
+            if (key == 1110) LDS_CASE(64, 128, 11, 1, false, 5, 16);
             break;
         case 32128:
-            if (key == 110) LDS_CASE(32, 128, 1, 1, false, 1);
-            if (key == 210) LDS_CASE(32, 128, 2, 1, false, 1);
-            if (key == 310) LDS_CASE(32, 128, 3, 1, false, 5);
-            if (key == 710) LDS_CASE(32, 128, 7, 1, false, 5);
-            if (key == 1110) LDS_CASE(32, 128, 11, 1, false, 5);
+            if (key == 110) LDS_CASE(32, 128, 1, 1, false, 1, 16);
+            if (key == 210) LDS_CASE(32, 128, 2, 1, false, 1, 16);
+            if (key == 310) LDS_CASE(32, 128, 3, 1, false, 5, 16);
+            if (key == 710) LDS_CASE(32, 128, 7, 1, false, 5, 16);
+            if (key == 1110) LDS_CASE(32, 128, 11, 1, false, 5, 16);
             break;
         default: break;
     }

@@ -31,6 +31,8 @@ struct ConvArgs {
     const float4* coef;      // NORM_ROWCOEF: [B][Ci] {mu, a, b, -}: v = (x-mu)*a + b
     const float* cmean; const float* crstd;   // NORM_COLSTAT: [B][Tsrc]
     const float* gamma; const float* beta;    // NORM_COLSTAT: [Ci]
+    const float2* lnpart; int ln_np; float ln_eps;   // NORM_COLSTAT alternative to cmean/crstd: [B][ln_np][Tsrc] (mean, M2)
+                                                     // partials over 32 channels each, combined in the kernel prologue
     int act_in; float slope;
     // epilogue
     const float* bias;       // [Co] (for GEGLU: packed order, Mp entries) or null
@@ -40,6 +42,7 @@ struct ConvArgs {
     int accum;               // 1: out = (out + y) / out_div  (MRF running sum), 0: out = y / out_div
     float out_div;           // 1.0 normally
     float* out;
+    float2* lnpart_out;      // optional [B][Cout/32][Tout]: per-frame (mean, M2) over each 32-channel group of the output
     int Cout;                // channels of `out` (Co, or Co/2 for GEGLU, or Co/phases for transposed conv)
     int To;                  // columns computed (N)
     // transposed-conv scatter: row m = co*phases + phi -> out[b][co][n*phases + phi - tpad] (phases=1: plain)
@@ -76,7 +79,7 @@ hipError_t launch_attention(const float* qkv, float* out, int B, int C, int T, i
 // ---------------------------------------------------------------------------------------------
 enum { IN_PLAIN = 0, IN_SILU = 1, IN_SINUSOID = 2 };
 hipError_t launch_small_linear(const float* W, const float* bias, const float* in, int in_stride, int in_mode,
-                               const float* freqs, float* out, int out_stride, int M, int K, int B, hipStream_t s);
+                               const float* freqs, float* out, int out_stride, int out_silu, int M, int K, int B, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Elementwise sampler updates over n = B*M*T elements

@@ -14,7 +14,7 @@ template <int BT>
 __global__ void __launch_bounds__(256) small_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                            const float* __restrict__ in, int in_stride, int in_mode,
                                                            const float* __restrict__ freqs, float* __restrict__ out,
-                                                           int out_stride, int M, int K, int B) {
+                                                           int out_stride, int out_silu, int M, int K, int B) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -51,17 +51,21 @@ __global__ void __launch_bounds__(256) small_linear_kernel(const float* __restri
             float v = acc[i];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0 && b0 + i < B) out[(long long)(b0 + i) * out_stride + m] = v + (bias ? bias[m] : 0.f);
+            if (lane == 0 && b0 + i < B) {
+                v += bias ? bias[m] : 0.f;
+                if (out_silu) v = v / (1.0f + expf(-v));
+                out[(long long)(b0 + i) * out_stride + m] = v;
+            }
         }
     }
 }
 
 hipError_t launch_small_linear(const float* W, const float* bias, const float* in, int in_stride, int in_mode,
-                               const float* freqs, float* out, int out_stride, int M, int K, int B, hipStream_t s) {
+                               const float* freqs, float* out, int out_stride, int out_silu, int M, int K, int B, hipStream_t s) {
     if (K % 4) return hipErrorInvalidValue;
     ProfScope ps(s, "small_linear", 2.0 * M * (double)K * B, 4.0 * M * (double)K);
-    hipLaunchKernelGGL(small_linear_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, s, W, bias, in, in_stride, in_mode, freqs, out,
-                       out_stride, M, K, B);
+    hipLaunchKernelGGL(small_linear_kernel<16>, dim3((M + 3) / 4), dim3(256), 0, s, W, bias, in, in_stride, in_mode, freqs, out,
+                       out_stride, out_silu, M, K, B);
     return hipGetLastError();
 }
 

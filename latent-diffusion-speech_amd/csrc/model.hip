@@ -210,6 +210,7 @@ struct ConvOpt {
     int stride = 1, pad = 0, dil = 1, ups = 0;
     int norm_mode = NORM_NONE; const float4* coef = nullptr;
     const float* cmean = nullptr; const float* crstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    const float2* lnpart = nullptr; int ln_np = 0; float ln_eps = 1e-5f; float2* lnpart_out = nullptr;
     int act_in = ACT_NONE; float slope = 0.f;
     const float* bias_bc = nullptr; const float* res = nullptr;
     int epi = EPI_NONE; int accum = 0; float out_div = 1.f;
@@ -226,6 +227,7 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.w = W.w; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
     a.stride = o.stride; a.dil = o.dil; a.pad = o.pad; a.ups = o.ups;
     a.norm_mode = o.norm_mode; a.coef = o.coef; a.cmean = o.cmean; a.crstd = o.crstd; a.gamma = o.gamma; a.beta = o.beta;
+    a.lnpart = o.lnpart; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.lnpart_out = o.lnpart_out;
     a.act_in = o.act_in; a.slope = o.slope;
     a.bias = W.bias; a.bias_bc = o.bias_bc; a.res = o.res; a.epi = o.epi; a.accum = o.accum; a.out_div = o.out_div;
     a.out = out;
@@ -507,7 +509,7 @@ static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
 struct UnetWs {
     float *e1, *emb, *tproj;
     float4* coef;
-    float *lmean, *lrstd;
+    float2* lnp;
     std::vector<float*> skips;
     float *cur[2], *r, *h1, *sc, *ta, *tb, *qkv, *att, *ff, *upt;
 };
@@ -519,8 +521,6 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.emb = A.f((size_t)B * u->temb);
     w.tproj = A.f((size_t)B * u->tp_M);
     w.coef = (float4*)A.f((size_t)B * u->max_ci * 4);
-    w.lmean = A.f((size_t)B * T);
-    w.lrstd = A.f((size_t)B * T);
     size_t maxct = 0, maxqkv = 0;
     int Tl = T;
     w.skips.clear();
@@ -554,6 +554,7 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.r = A.f(B * maxct); w.h1 = A.f(B * maxct); w.sc = A.f(B * maxct);
     w.ta = A.f(B * maxct); w.tb = A.f(B * maxct); w.upt = A.f(B * maxct);
     w.qkv = A.f(B * maxqkv * 3); w.att = A.f(B * maxqkv); w.ff = A.f(B * maxqkv * 4);
+    w.lnp = (float2*)A.f(B * (maxqkv / 32) * 2);
 }
 
 extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t* out) {
@@ -589,32 +590,31 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
 }
 
 static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st) {
-    // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major
+    // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major.  Every conv that feeds a
+    // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer combines them on load.
     const int C = t.C;
     HIP_TRY(launch_gn_coef(x, x, C, 0, T, (long long)C * T, 0, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, w.coef, B, st));
     Src sx{x, C, nullptr, 0, T};
     ConvOpt op;
-    op.norm_mode = NORM_ROWCOEF; op.coef = w.coef;
+    op.norm_mode = NORM_ROWCOEF; op.coef = w.coef; op.lnpart_out = w.lnp;
     LDS_TRY(run_conv(t.proj_in, sx, op, w.ta, B, st));
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
-        HIP_TRY(launch_ln_stats(h, C, T, 1e-5f, w.lmean, w.lrstd, B, st));
         Src sh{h, C, nullptr, 0, T};
         ConvOpt oq;
-        oq.norm_mode = NORM_COLSTAT; oq.cmean = w.lmean; oq.crstd = w.lrstd; oq.gamma = t.ln_g[a]; oq.beta = t.ln_b[a];
+        oq.norm_mode = NORM_COLSTAT; oq.lnpart = w.lnp; oq.ln_np = C / 32; oq.ln_eps = 1e-5f; oq.gamma = t.ln_g[a]; oq.beta = t.ln_b[a];
         LDS_TRY(run_conv(t.qkv[a], sh, oq, w.qkv, B, st));
         { ProfScope ps(st, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T); HIP_TRY(launch_attention(w.qkv, w.att, B, C, T, u->heads, st)); }
         Src sa{w.att, C, nullptr, 0, T};
         ConvOpt oo;
-        oo.res = h;
+        oo.res = h; oo.lnpart_out = w.lnp;
         LDS_TRY(run_conv(t.o[a], sa, oo, hn, B, st));
         float* tmp = h; h = hn; hn = tmp;
     }
-    HIP_TRY(launch_ln_stats(h, C, T, 1e-5f, w.lmean, w.lrstd, B, st));
     Src sh{h, C, nullptr, 0, T};
     ConvOpt of;
-    of.norm_mode = NORM_COLSTAT; of.cmean = w.lmean; of.crstd = w.lrstd; of.gamma = t.ln_g[2]; of.beta = t.ln_b[2];
+    of.norm_mode = NORM_COLSTAT; of.lnpart = w.lnp; of.ln_np = C / 32; of.ln_eps = 1e-5f; of.gamma = t.ln_g[2]; of.beta = t.ln_b[2];
     of.epi = EPI_GEGLU;
     LDS_TRY(run_conv(t.ff1, sh, of, w.ff, B, st));
     Src sf{w.ff, 4 * C, nullptr, 0, T};
@@ -635,9 +635,11 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
     const int nb = u->cfg.n_blocks;
     // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch
-    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, u->temb, u->tproj_dim, B, st));
-    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_SILU, nullptr, w.emb, u->temb, u->temb, u->temb, B, st));
-    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_SILU, nullptr, w.tproj, u->tp_M, u->tp_M, u->temb, B, st));
+    // e1 = SiLU(linear_1(sinusoid(t))); emb = SiLU(linear_2(e1)) -- every consumer of emb applies SiLU first
+    // (resnet.py:610), so only the activated embedding is stored
+    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, 1, u->temb, u->tproj_dim, B, st));
+    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_PLAIN, nullptr, w.emb, u->temb, 1, u->temb, u->temb, B, st));
+    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_PLAIN, nullptr, w.tproj, u->tp_M, 0, u->tp_M, u->temb, B, st));
     // conv_in over the virtual concat [x ; cond] (reference diffusion.py:105, unet_1d_condition.py:943)
     size_t si = 0;
     {
@@ -1127,6 +1129,30 @@ extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* st
     Src s{a->x1, a->C1, a->x2, a->C2, T};
     int r = run_conv(W, s, o, out, B, st);
     HIP_TRY(hipStreamSynchronize(st));   // test-only entry point: temporaries are freed on return
+    return r;
+}
+
+// conv1 (1x1, emits LayerNorm partials) -> conv2 (1x1, LayerNorm-on-load from those partials)
+extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
+                                 float* mid, float* out, int B, int C, int Co, int T, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    ConvW W1, W2;
+    if (!pack_conv(own, w1, nullptr, C, C, 1, W1) || !pack_conv(own, w2, nullptr, Co, C, 1, W2)) return fail(LDS_ENOMEM, "upload failed");
+    float* g = up_vec(own, gamma, C);
+    float* be = up_vec(own, beta, C);
+    void* part = nullptr;
+    HIP_TRY(hipMalloc(&part, (size_t)B * (C / 32) * T * sizeof(float2)));
+    own.ptrs.push_back(part);
+    Src s1{x, C, nullptr, 0, T};
+    ConvOpt o1;
+    o1.lnpart_out = (float2*)part;
+    LDS_TRY(run_conv(W1, s1, o1, mid, B, st));
+    Src s2{mid, C, nullptr, 0, T};
+    ConvOpt o2;
+    o2.norm_mode = NORM_COLSTAT; o2.lnpart = (const float2*)part; o2.ln_np = C / 32; o2.ln_eps = eps; o2.gamma = g; o2.beta = be;
+    int r = run_conv(W2, s2, o2, out, B, st);
+    HIP_TRY(hipStreamSynchronize(st));
     return r;
 }
 

@@ -241,3 +241,29 @@ def test_transpose_and_axpby():
     a, b = U("ax.a", (1000,)), U("ax.b", (1000,))
     z = native.axpby(dev(a), dev(b), 0.25, 3.0).cpu().numpy()
     assert np.allclose(z, 0.25 * a + 3.0 * b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,Co,T,B", [(256, 768, 64, 2), (384, 384, 100, 1), (512, 1536, 37, 2)])
+def test_layernorm_partials_chain(C, Co, T, B):
+    """conv1 emits per-32-channel (mean, M2) partials in its epilogue; conv2 combines them (Chan) and applies
+    LayerNorm over channels while staging its input -- no standalone LayerNorm pass exists in the UNet path."""
+    _need_gpu()
+    from lds import native
+    from oracle import unet1d
+    x = U(f"lnc{C}.x", (B, C, T), -2, 2)
+    w1 = (U(f"lnc{C}.w1", (C, C)) / np.float32(np.sqrt(C))).astype(np.float32)
+    w2 = (U(f"lnc{C}.w2", (Co, C)) / np.float32(np.sqrt(C))).astype(np.float32)
+    g, be = U(f"lnc{C}.g", (C,), 0.5, 1.5), U(f"lnc{C}.b", (C,), -0.5, 0.5)
+    mid = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.full((B, Co, T), float("nan"), dtype=torch.float32, device="cuda")
+    dx = dev(x)
+    native.check(native.lib().lds_test_ln_chain(ct.c_void_p(dx.data_ptr()), ct.c_void_p(w1.ctypes.data), ct.c_void_p(w2.ctypes.data),
+                                                ct.c_void_p(g.ctypes.data), ct.c_void_p(be.ctypes.data), ct.c_float(1e-5),
+                                                ct.c_void_p(mid.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, Co, T,
+                                                ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    rmid = unet1d.conv1d(x, w1[:, :, None])
+    rn = unet1d.layer_norm(rmid.transpose(0, 2, 1), g, be, 1e-5).transpose(0, 2, 1)
+    ref = unet1d.conv1d(np.ascontiguousarray(rn), w2[:, :, None])
+    assert relmax(mid.cpu().numpy(), rmid) < 2e-5
+    assert relmax(out.cpu().numpy(), ref) < 2e-5, relmax(out.cpu().numpy(), ref)
