@@ -156,6 +156,9 @@ typedef struct {
     int tile;                           /* 0 auto, else BM*1000+BN                                */
 } lds_conv_test;
 int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream);
+/* the same op launched `iters` times back to back; *ms_out = mean launch duration from HIP events on `stream` */
+int lds_bench_conv(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
+                   void* stream);
 /* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
 /* mid = w1*x (1x1, [C,C]); out = w2 * LayerNorm_C(mid) (1x1, [Co,C]); statistics travel as epilogue partials */
 int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,

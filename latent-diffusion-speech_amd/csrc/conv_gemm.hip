@@ -238,22 +238,54 @@ struct ConvKernel {
         }
     }
 
-    __device__ __forceinline__ void mfma_group(const float* st, int tap, int k2) {
+    // MFMA operands are read from LDS NB-1 groups ahead of their use into a small register ring, so the
+    // LDS latency is covered by the 64-cycle MFMAs in between instead of being paid before every MFMA
+    static constexpr int NB = 4;
+    float aop[NB][TM], bop[NB][TN];
+
+    template <int SLOT>
+    __device__ __forceinline__ void load_ops(const float* st, int tap, int k2) {
         const float* wt = st + tap * BK * BM + arow;
         const float* xs = st + KT * BK * BM;
         const int k = 2 * k2 + h;
-        float a[TM], bv[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = wt[k * BM + i * 32];
+        for (int i = 0; i < TM; ++i) aop[SLOT][i] = wt[k * BM + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - s_al) : (bcol[j] + tap * p.dil);
-            bv[j] = xs[k * xwp + col];
+            bop[SLOT][j] = xs[k * xwp + col];
         }
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void mfma_ops() {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[SLOT][i], bop[SLOT][j], acc[i][j], 0, 0, 0);
+    }
+    // the BK/2 groups of one (runtime) tap, operands prefetched NB-1 groups ahead (vocoder taps 7 / 11)
+    template <int k2>
+    __device__ __forceinline__ void tap_groups(const float* st, int tap) {
+        if constexpr (k2 < BK / 2) {
+            if constexpr (k2 == 0) {
+                load_ops<0>(st, tap, 0);
+                load_ops<1>(st, tap, 1);
+                load_ops<2>(st, tap, 2);
+            }
+            if constexpr (k2 + NB - 1 < BK / 2) load_ops<(k2 + NB - 1) % NB>(st, tap, k2 + NB - 1);
+            mfma_ops<k2 % NB>();
+            __builtin_amdgcn_sched_barrier(0);
+            tap_groups<k2 + 1>(st, tap);
+        }
+    }
+
+    template <int g0, int g1>
+    __device__ __forceinline__ void preload(const float* cur) {
+        if constexpr (g0 < g1 && g0 < G) {
+            load_ops<g0 % NB>(cur, g0 / (BK / 2), g0 % (BK / 2));
+            preload<g0 + 1, g1>(cur);
+        }
     }
 
     // one K-step, fully unrolled: the first half of the MFMA groups carries the commit pieces of tile kc+1,
@@ -261,6 +293,8 @@ struct ConvKernel {
     template <int g>
     __device__ __forceinline__ void kstep(const float* cur, float* nxt, bool do_commit, bool do_fetch, int kc) {
         if constexpr (g < G) {
+            if constexpr (g == 0) preload<0, NB - 1>(cur);
+            if constexpr (g + NB - 1 < G) load_ops<(g + NB - 1) % NB>(cur, (g + NB - 1) / (BK / 2), (g + NB - 1) % (BK / 2));
             if constexpr (g < HALF) {
                 constexpr int p_lo = (g * P) / HALF, p_hi = ((g + 1) * P) / HALF;
                 if (do_commit) commit_range<p_lo, p_hi>(nxt);
@@ -268,7 +302,10 @@ struct ConvKernel {
             if constexpr (g == HALF) {
                 if (do_fetch) fetch(kc + 2);
             }
-            mfma_group(cur, g / (BK / 2), g % (BK / 2));
+            mfma_ops<g % NB>();
+            // pin the software pipeline: without this the machine scheduler sinks every operand read back next to
+            // its MFMA (ds_read; s_waitcnt lgkmcnt(0); v_mfma), exposing the LDS latency 32-96 times per K-step
+            __builtin_amdgcn_sched_barrier(0);
             kstep<g + 1>(cur, nxt, do_commit, do_fetch, kc);
         }
     }
@@ -289,10 +326,7 @@ struct ConvKernel {
                 if (do_commit) commit_range<0, P>(nxt);
                 if (do_fetch) fetch(kc + 2);
 #pragma unroll 1
-                for (int tap = 0; tap < KT; ++tap) {
-#pragma unroll
-                    for (int k2 = 0; k2 < BK / 2; ++k2) mfma_group(cur, tap, k2);
-                }
+                for (int tap = 0; tap < KT; ++tap) tap_groups<0>(cur, tap);
             }
             __syncthreads();
         }

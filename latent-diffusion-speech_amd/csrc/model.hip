@@ -1090,7 +1090,7 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
 // ================================================================================================
 // Single-op test entry points
 // ================================================================================================
-extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream) {
+static int test_conv_impl(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, void* stream) {
     if (!a || !out) return fail(LDS_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     Owner own;
@@ -1128,9 +1128,38 @@ extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* st
     }
     Src s{a->x1, a->C1, a->x2, a->C2, T};
     int r = run_conv(W, s, o, out, B, st);
+    if (r == LDS_OK && iters > 0 && ms_out) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+        for (int i = 0; i < iters && r == LDS_OK; ++i) r = run_conv(W, s, o, out, B, st);
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     HIP_TRY(hipStreamSynchronize(st));   // test-only entry point: temporaries are freed on return
     return r;
 }
+
+extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream) {
+    if (!a || !out) return fail(LDS_EINVAL, "bad argument");
+    return test_conv_impl(a, out, B, 0, nullptr, stream);
+}
+
+// same op launched `iters` times back to back (weights packed once); *ms_out = average kernel time from HIP events
+extern "C" int lds_bench_conv(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
+                              void* stream) {
+    if (!a || !out || !ms_out || iters <= 0) return fail(LDS_EINVAL, "bad argument");
+    int r = test_conv_impl(a, out, B, iters, ms_out, stream);
+    if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_gemm_last_config());
+    return r;
+}
+
 
 // conv1 (1x1, emits LayerNorm partials) -> conv2 (1x1, LayerNorm-on-load from those partials)
 extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,

@@ -39,7 +39,7 @@ EXPORTS = [
     "lds_last_error", "lds_version", "lds_unet_create", "lds_unet_destroy", "lds_unet_workspace_bytes",
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
-    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_ln_chain", "lds_test_attention",
+    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_bench_conv", "lds_test_ln_chain", "lds_test_attention",
     "lds_test_conv_transpose"]
 
 
