@@ -30,7 +30,9 @@ namespace lds {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + expf(-v)); }
+// SiLU on the staging path: hardware exp2 / rcp (about 1 ulp each); the extra ~2e-7 relative error is far inside
+// the stated 2e-5 UNet tolerance and keeps the transform at ~6 VALU ops per element
+static __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
 
 static __device__ __forceinline__ int floor4(int s) { return (s >= 0) ? (s & ~3) : -(((-s) + 3) & ~3); }
 
@@ -40,14 +42,16 @@ struct ConvCfg {
     static constexpr int WAVES_N = 4 / WAVES_M;
     static constexpr int TM = BM / (32 * WAVES_M);
     static constexpr int TN = BN / (32 * WAVES_N);
-    static constexpr int TPR = 256 / BK;   // threads that stage one activation row
+    static constexpr int KR = BK / 4;       // staged "k-rows": (kq, h) pairs, each holding 4 k values per column
+    static constexpr int TPR = 256 / KR;    // threads that stage one k-row of activations
     static constexpr int XWMAX = UPS ? (BN / 2 + 2 + 3) : ((BN - 1) * STRIDE + (KT - 1) * DILMAX + 1 + 3);
     static constexpr int XW4MAX = (XWMAX + 3) / 4;
-    static constexpr int XCH = (XW4MAX + TPR - 1) / TPR;
-    static constexpr int WCHUNKS = KT * BK * BM / 4;
+    static constexpr int XCH = (XW4MAX + TPR - 1) / TPR;   // 4-frame chunks per thread (x 4 channel rows each)
+    static constexpr int WCHUNKS = KT * KR * BM;           // float4 chunks of the weight tile
     static constexpr int WCH = (WCHUNKS + 255) / 256;
-    static constexpr int G = KT * BK / 2;          // MFMA groups (one k-pair of one tap) per K-step
-    static constexpr bool INTERLEAVE = (KT <= 3);  // fully unrolled K-step with commit pieces between MFMAs
+    static constexpr int G = KT * BK / 8;                  // MFMA groups per K-step: one (tap, kq) = 4 k-pairs
+    static constexpr bool INTERLEAVE = (KT <= 3);          // fully unrolled K-step with commit pieces between MFMA groups
+    static constexpr int NB = (TM * TN >= 4) ? 2 : 3;      // operand ring depth (groups)
     static constexpr size_t lds_bytes(int xw4) { return (size_t)(2 * (KT * BK * BM + BK * xw4 * 4) + 2 * xw4 * 4) * sizeof(float); }
 };
 
@@ -55,12 +59,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // All per-thread state lives in one struct whose methods are force-inlined: every register array is a
 // member indexed by compile-time constants (template recursion), so nothing falls back to scratch.
+//
+// k-interleaved tiles: v_mfma_f32_32x32x2_f32 takes ONE scalar of A and B per lane (lane half h supplies
+// k = 2*kp + h), so a naive [k][n] LDS image costs one ds_read_b32 per operand per MFMA and the kernel becomes
+// LDS-latency / issue bound.  Both tiles are therefore stored as [kq][h][column][4] with
+// k = 8*kq + 2*j + h (j = float4 element): one ds_read_b128 per lane delivers the operands of FOUR
+// consecutive MFMAs.  The weights are packed that way once on the host; the activations are transposed for
+// free in registers (each staging thread loads the same 4 frames of 4 channel rows and writes 4 float4s).
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
 struct ConvKernel {
     using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
-    static constexpr int TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH, TPR = Cfg::TPR, G = Cfg::G;
-    static constexpr int P = XCH + WCH;      // commit pieces per K-step
-    static constexpr int HALF = G / 2;
+    static constexpr int TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH, TPR = Cfg::TPR, G = Cfg::G, KR = Cfg::KR;
+    static constexpr int NB = Cfg::NB;
+    static constexpr int P = XCH * 4 + WCH;      // commit pieces per K-step (one ds_write_b128 each)
+    static constexpr int HALF = (G / 2 > 0) ? G / 2 : 1;
 
     const ConvArgs& p;
     float* smem;
@@ -68,12 +80,13 @@ struct ConvKernel {
     int s_al, off, xw4, xwp, stage;
     float* cst;
     bool vec_ok;
-    int xrow, xc0, arow;
+    int xrr, xc0, arow;
     int bcol[TN];
-    f32x4 xr[XCH];
+    f32x4 xr[XCH][4];                  // [chunk][channel row j] = 4 frames
     f32x4 wr[WCH];
-    float cf0, cf1, cf2;               // ROWCOEF: mu, a, b ; COLSTAT: gamma, beta
+    float cfa[4], cfb[4], cfc[4];      // per staged channel row: ROWCOEF mu, a, b ; COLSTAT gamma, beta
     f32x16 acc[TM][TN];
+    f32x4 aop[NB][TM], bop[NB][TN];
 
     __device__ __forceinline__ ConvKernel(const ConvArgs& p_, float* smem_) : p(p_), smem(smem_) {}
 
@@ -103,8 +116,8 @@ struct ConvKernel {
         stage = KT * BK * BM + BK * xwp;   // floats per LDS stage
         cst = smem + 2 * stage;            // [2][xwp] LayerNorm mean / rstd of the window's frames
         vec_ok = ((p.Tsrc & 3) == 0);
-        xrow = tid / TPR;                  // one activation row per thread, chunks xc0, xc0+TPR, ...
-        xc0 = tid - xrow * TPR;
+        xrr = tid / TPR;                   // staged k-row (kq*2 + h') of this thread, chunks xc0, xc0+TPR, ...
+        xc0 = tid - xrr * TPR;
         arow = wm * TM * 32 + c;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -117,7 +130,14 @@ struct ConvKernel {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        cf0 = 0.f; cf1 = 1.f; cf2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cfa[j] = 0.f; cfb[j] = 1.f; cfc[j] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < XCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) wr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // LayerNorm over channels (reference attention.py:83,102,118): per-frame mean / rstd for this window
@@ -148,12 +168,20 @@ struct ConvKernel {
         }
     }
 
-    template <int I>
-    __device__ __forceinline__ void fetch_x(const float* src) {
+    // channel of row j (0..3) staged by this thread in K-step kc: k = 8*kq + 2*j + h'
+    __device__ __forceinline__ int chan(int kc, int j) const { return kc * BK + 8 * (xrr >> 1) + 2 * j + (xrr & 1); }
+    __device__ __forceinline__ const float* rowptr(int ci) const {
+        return (ci < p.C1) ? (p.x1 + (long long)b * p.xb1 + (long long)ci * p.Tsrc)
+                           : (p.x2 + (long long)b * p.xb2 + (long long)(ci - p.C1) * p.Tsrc);
+    }
+
+    template <int I, int J>
+    __device__ __forceinline__ void fetch_x(int kc) {
         if constexpr (I < XCH) {
             const int c4 = xc0 + I * TPR;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c4 < xw4) {
+                const float* src = rowptr(chan(kc, J));
                 const int s = s_al + c4 * 4;
                 if (vec_ok && s >= 0 && s + 3 < p.Tsrc) {
                     v = *reinterpret_cast<const f32x4*>(src + s);
@@ -162,8 +190,9 @@ struct ConvKernel {
                     for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < p.Tsrc) ? src[s + e] : 0.f;
                 }
             }
-            xr[I] = v;
-            fetch_x<I + 1>(src);
+            xr[I][J] = v;
+            if constexpr (J < 3) fetch_x<I, J + 1>(kc);
+            else fetch_x<I + 1, 0>(kc);
         }
     }
     template <int J>
@@ -172,28 +201,35 @@ struct ConvKernel {
             const int q = tid + J * 256;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < Cfg::WCHUNKS) {
-                const int tap = q / (BK * BM / 4);
-                const int rem = q - tap * (BK * BM / 4);
-                const int k = rem / (BM / 4), m4 = rem - k * (BM / 4);
-                v = *reinterpret_cast<const f32x4*>(p.w + ((long long)(tap * p.Ci + kc * BK + k)) * p.Mp + m0 + 4 * m4);
+                const int tap = q / (KR * BM);
+                const int rem = q - tap * (KR * BM);
+                const int rr = rem / BM, m = rem - rr * BM;
+                v = *reinterpret_cast<const f32x4*>(p.w + ((long long)(tap * (p.Ci / 4) + kc * KR + rr) * p.Mp + m0 + m) * 4);
             }
             wr[J] = v;
             fetch_w<J + 1>(kc);
         }
     }
-    __device__ __forceinline__ void fetch(int kc) {
-        const int ci = kc * BK + xrow;
-        const float* src = (ci < p.C1) ? (p.x1 + (long long)b * p.xb1 + (long long)ci * p.Tsrc)
-                                       : (p.x2 + (long long)b * p.xb2 + (long long)(ci - p.C1) * p.Tsrc);
-        fetch_x<0>(src);
-        float a0 = 0.f, a1 = 1.f, a2 = 0.f;
-        if (p.norm_mode == NORM_ROWCOEF) {
-            const float4 cf = p.coef[(long long)b * p.Ci + ci];
-            a0 = cf.x; a1 = cf.y; a2 = cf.z;
-        } else if (p.norm_mode == NORM_COLSTAT) {
-            a0 = p.gamma[ci]; a1 = p.beta[ci];
+    template <int J>
+    __device__ __forceinline__ void fetch_coef(int kc) {
+        if constexpr (J < 4) {
+            float a0 = 0.f, a1 = 1.f, a2 = 0.f;
+            if (p.norm_mode == NORM_ROWCOEF) {
+                const float4 cf = p.coef[(long long)b * p.Ci + chan(kc, J)];
+                a0 = cf.x; a1 = cf.y; a2 = cf.z;
+            } else if (p.norm_mode == NORM_COLSTAT) {
+                a0 = p.gamma[chan(kc, J)]; a1 = p.beta[chan(kc, J)];
+            }
+            cfa[J] = a0; cfb[J] = a1; cfc[J] = a2;
+            fetch_coef<J + 1>(kc);
         }
-        cf0 = a0; cf1 = a1; cf2 = a2;
+    }
+    __device__ __forceinline__ void fetch(int kc) {
+        if (p.dbg & 1) return;
+        if (xrr < KR) {
+            fetch_x<0, 0>(kc);
+            fetch_coef<0>(kc);
+        }
         fetch_w<0>(kc);
     }
 
@@ -203,29 +239,34 @@ struct ConvKernel {
         return v;
     }
 
-    // piece PC of the staged tile: PC < XCH -> activation chunk (transform + ds_write), else weight chunk
+    // piece PC of the staged tile: PC < 4*XCH -> one frame of an activation chunk (transform of 4 channel rows +
+    // one ds_write_b128), else one weight chunk
     template <int PC>
     __device__ __forceinline__ void commit_piece(float* st) {
-        if constexpr (PC < XCH) {
-            const int c4 = xc0 + PC * TPR;
-            if (c4 < xw4) {
-                const int s = s_al + c4 * 4;
-                f32x4 v = xr[PC];
-                if (p.norm_mode == NORM_COLSTAT) {
-                    const f32x4 mu = *reinterpret_cast<const f32x4*>(cst + c4 * 4);
-                    const f32x4 rs = *reinterpret_cast<const f32x4*>(cst + xwp + c4 * 4);
+        if (p.dbg & 2) return;
+        if constexpr (PC < XCH * 4) {
+            constexpr int I = PC / 4, E = PC % 4;
+            const int c4 = xc0 + I * TPR;
+            if (xrr < KR && c4 < xw4) {
+                const int s = s_al + c4 * 4 + E;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (s >= 0 && s < p.Tsrc) {
+                    if (p.norm_mode == NORM_COLSTAT) {
+                        const float mu = cst[c4 * 4 + E], rs = cst[xwp + c4 * 4 + E];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * (rs[e] * cf0) + cf1;
-                } else if (p.norm_mode == NORM_ROWCOEF) {
+                        for (int j = 0; j < 4; ++j) v[j] = act((xr[I][j][E] - mu) * (rs * cfa[j]) + cfb[j]);
+                    } else if (p.norm_mode == NORM_ROWCOEF) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] - cf0) * cf1 + cf2;
+                        for (int j = 0; j < 4; ++j) v[j] = act((xr[I][j][E] - cfa[j]) * cfb[j] + cfc[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = act(xr[I][j][E]);
+                    }
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < p.Tsrc) ? act(v[e]) : 0.f;
-                *reinterpret_cast<f32x4*>(st + KT * BK * BM + xrow * xwp + c4 * 4) = v;
+                *reinterpret_cast<f32x4*>(st + KT * BK * BM + (xrr * xwp + c4 * 4 + E) * 4) = v;
             }
         } else {
-            constexpr int J = PC - XCH;
+            constexpr int J = PC - XCH * 4;
             const int q = tid + J * 256;
             if (q < Cfg::WCHUNKS) *reinterpret_cast<f32x4*>(st + 4 * q) = wr[J];
         }
@@ -238,52 +279,36 @@ struct ConvKernel {
         }
     }
 
-    // MFMA operands are read from LDS NB-1 groups ahead of their use into a small register ring, so the
-    // LDS latency is covered by the 64-cycle MFMAs in between instead of being paid before every MFMA
-    static constexpr int NB = 4;
-    float aop[NB][TM], bop[NB][TN];
-
+    // MFMA operands of group (tap, kq) are read from LDS NB-1 groups ahead of their use into a small register
+    // ring, so the LDS latency is covered by the MFMAs in between
     template <int SLOT>
-    __device__ __forceinline__ void load_ops(const float* st, int tap, int k2) {
-        const float* wt = st + tap * BK * BM + arow;
-        const float* xs = st + KT * BK * BM;
-        const int k = 2 * k2 + h;
+    __device__ __forceinline__ void load_ops(const float* st, int tap, int kq) {
+        const float* wt = st + ((tap * KR + kq * 2 + h) * BM + arow) * 4;
+        const float* xs = st + KT * BK * BM + (kq * 2 + h) * xwp * 4;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) aop[SLOT][i] = wt[k * BM + i * 32];
+        for (int i = 0; i < TM; ++i) aop[SLOT][i] = *reinterpret_cast<const f32x4*>(wt + i * 32 * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - s_al) : (bcol[j] + tap * p.dil);
-            bop[SLOT][j] = xs[k * xwp + col];
+            bop[SLOT][j] = *reinterpret_cast<const f32x4*>(xs + col * 4);
         }
     }
     template <int SLOT>
     __device__ __forceinline__ void mfma_ops() {
+        if (p.dbg & 4) return;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[SLOT][i], bop[SLOT][j], acc[i][j], 0, 0, 0);
-    }
-    // the BK/2 groups of one (runtime) tap, operands prefetched NB-1 groups ahead (vocoder taps 7 / 11)
-    template <int k2>
-    __device__ __forceinline__ void tap_groups(const float* st, int tap) {
-        if constexpr (k2 < BK / 2) {
-            if constexpr (k2 == 0) {
-                load_ops<0>(st, tap, 0);
-                load_ops<1>(st, tap, 1);
-                load_ops<2>(st, tap, 2);
-            }
-            if constexpr (k2 + NB - 1 < BK / 2) load_ops<(k2 + NB - 1) % NB>(st, tap, k2 + NB - 1);
-            mfma_ops<k2 % NB>();
-            __builtin_amdgcn_sched_barrier(0);
-            tap_groups<k2 + 1>(st, tap);
-        }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[SLOT][i][jj], bop[SLOT][j][jj], acc[i][j], 0, 0, 0);
     }
 
     template <int g0, int g1>
     __device__ __forceinline__ void preload(const float* cur) {
         if constexpr (g0 < g1 && g0 < G) {
-            load_ops<g0 % NB>(cur, g0 / (BK / 2), g0 % (BK / 2));
+            load_ops<g0 % NB>(cur, g0 / (BK / 8), g0 % (BK / 8));
             preload<g0 + 1, g1>(cur);
         }
     }
@@ -294,19 +319,31 @@ struct ConvKernel {
     __device__ __forceinline__ void kstep(const float* cur, float* nxt, bool do_commit, bool do_fetch, int kc) {
         if constexpr (g < G) {
             if constexpr (g == 0) preload<0, NB - 1>(cur);
-            if constexpr (g + NB - 1 < G) load_ops<(g + NB - 1) % NB>(cur, (g + NB - 1) / (BK / 2), (g + NB - 1) % (BK / 2));
+            if constexpr (g + NB - 1 < G) load_ops<(g + NB - 1) % NB>(cur, (g + NB - 1) / (BK / 8), (g + NB - 1) % (BK / 8));
             if constexpr (g < HALF) {
                 constexpr int p_lo = (g * P) / HALF, p_hi = ((g + 1) * P) / HALF;
                 if (do_commit) commit_range<p_lo, p_hi>(nxt);
             }
-            if constexpr (g == HALF) {
+            if constexpr (g == HALF || (G == 1 && g == 0)) {
                 if (do_fetch) fetch(kc + 2);
             }
             mfma_ops<g % NB>();
-            // pin the software pipeline: without this the machine scheduler sinks every operand read back next to
-            // its MFMA (ds_read; s_waitcnt lgkmcnt(0); v_mfma), exposing the LDS latency 32-96 times per K-step
+            // pin the software pipeline: otherwise the machine scheduler sinks every operand read back next to its
+            // MFMA (ds_read; s_waitcnt lgkmcnt(0); v_mfma) and the LDS latency is exposed once per group
             __builtin_amdgcn_sched_barrier(0);
             kstep<g + 1>(cur, nxt, do_commit, do_fetch, kc);
+        }
+    }
+
+    // the BK/8 groups of one (runtime) tap (vocoder taps 7 / 11)
+    template <int kq>
+    __device__ __forceinline__ void tap_groups(const float* st, int tap) {
+        if constexpr (kq < BK / 8) {
+            if constexpr (kq == 0) load_ops<0>(st, tap, 0);
+            if constexpr (kq + 1 < BK / 8) load_ops<(kq + 1) % NB>(st, tap, kq + 1);
+            mfma_ops<kq % NB>();
+            __builtin_amdgcn_sched_barrier(0);
+            tap_groups<kq + 1>(st, tap);
         }
     }
 

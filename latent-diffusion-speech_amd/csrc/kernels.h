@@ -48,6 +48,7 @@ struct ConvArgs {
     // transposed-conv scatter: row m = co*phases + phi -> out[b][co][n*phases + phi - tpad] (phases=1: plain)
     int phases, tpad, Tout;  // Tout = row length of out
     int B;
+    int dbg;                 // diagnostics only (tools/bench_conv.py, LDS_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA
 };
 
 // tile: 0 = auto, else BM*1000+BN in {128128, 64064, 128064, 64128, 32128}

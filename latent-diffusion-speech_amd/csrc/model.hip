@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -135,13 +136,18 @@ struct ConvW {
 
 static int round_mp(int Co) { return Co <= 32 ? 32 : (Co + 63) / 64 * 64; }
 
+// packed weight index (see conv_gemm.hip, "k-interleaved tiles"): [tap][k/8][k%2][Mp][(k%8)/2]
+static inline size_t widx(int tap, int k, int m, int Ci, int Mp) {
+    return ((((size_t)tap * (Ci / 8) + k / 8) * 2 + (k & 1)) * Mp + m) * 4 + ((k & 7) >> 1);
+}
+
 // reference layout w[Co][Ci][K] (or [Co][Ci] for Linear) -> packed
 static bool pack_conv(Owner& o, const float* w, const float* b, int Co, int Ci, int K, ConvW& out) {
     const int Mp = round_mp(Co);
     std::vector<float> p((size_t)K * Ci * Mp, 0.f), pb(Mp, 0.f);
     for (int co = 0; co < Co; ++co)
         for (int ci = 0; ci < Ci; ++ci)
-            for (int k = 0; k < K; ++k) p[((size_t)k * Ci + ci) * Mp + co] = w[((size_t)co * Ci + ci) * K + k];
+            for (int k = 0; k < K; ++k) p[widx(k, ci, co, Ci, Mp)] = w[((size_t)co * Ci + ci) * K + k];
     if (b)
         for (int co = 0; co < Co; ++co) pb[co] = b[co];
     out.w = o.upload(p);
@@ -158,7 +164,7 @@ static bool pack_geglu(Owner& o, const float* w, const float* b, int C8, int Ci,
     for (int m = 0; m < C8; ++m) {
         const int q = m / 64, s = (m % 64) / 32, r = m % 32;
         const int src = (s == 0 ? 0 : half) + 32 * q + r;
-        for (int ci = 0; ci < Ci; ++ci) p[(size_t)ci * C8 + m] = w[(size_t)src * Ci + ci];
+        for (int ci = 0; ci < Ci; ++ci) p[widx(0, ci, m, Ci, C8)] = w[(size_t)src * Ci + ci];
         pb[m] = b[src];
     }
     out.w = o.upload(p);
@@ -176,7 +182,7 @@ static bool pack_convT(Owner& o, const float* w, const float* b, int Ci, int Co,
         for (int ci = 0; ci < Ci; ++ci)
             for (int co = 0; co < Co; ++co)
                 for (int phi = 0; phi < stride; ++phi)
-                    p[((size_t)tap * Ci + ci) * Mp + co * stride + phi] = w[((size_t)ci * Co + co) * K + phi + stride * (KT - 1 - tap)];
+                    p[widx(tap, ci, co * stride + phi, Ci, Mp)] = w[((size_t)ci * Co + co) * K + phi + stride * (KT - 1 - tap)];
     for (int co = 0; co < Co; ++co)
         for (int phi = 0; phi < stride; ++phi) pb[co * stride + phi] = b ? b[co] : 0.f;
     out.w = o.upload(p);
@@ -238,6 +244,7 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.phases = o.phases; a.tpad = o.tpad;
     a.Cout = o.Cout > 0 ? o.Cout : (o.epi == EPI_GEGLU ? W.Co / 2 : W.Co / o.phases);
     a.B = B;
+    { static const char* d = getenv("LDS_DBG"); a.dbg = d ? atoi(d) : 0; }
     const double real_rows = (o.epi == EPI_GEGLU || o.phases > 1) ? (double)W.Co : (double)(a.Cout);
     const double flops = 2.0 * B * (double)a.To * real_rows * (double)W.Ci * (double)W.K;
     const double bytes = 4.0 * ((double)B * W.Ci * s.Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.Tout * (o.res ? 2.0 : 1.0));
