@@ -17,10 +17,13 @@
 // normalised tensors are never materialised in HBM.  A second source pointer implements the
 // UNet's skip-concat on read; `ups` reads a 2x nearest-upsampled view of the source.
 //
-// Pipeline: LDS is double buffered, one barrier per K-step.  Global loads for tile k+2 are issued
-// in the middle of tile k's MFMAs; the transform + LDS writes of tile k+1 are interleaved with the
-// first half of tile k's MFMAs (an fp32 MFMA occupies the matrix pipe for 64 cycles and leaves the
-// wave free to issue VALU / DS work), so at one wave per SIMD the matrix pipe stays busy.
+// Pipeline: producer / consumer wave specialisation.  A workgroup is 8 waves: waves 4-7 (one per SIMD)
+// fetch the next tiles from global memory, apply the normalisation / activation and write the
+// double-buffered LDS stages; waves 0-3 (one per SIMD) only read LDS operands and issue MFMAs.  The
+// matrix pipe and the VALU are separate pipes of a SIMD, so the producers' address / transform work
+// runs beside the consumers' MFMA chain instead of in front of it (measured on the single-role
+// version: 37 % of wave time went to issuing VALU/LDS work, 33 % to waits, 25 % to MFMA).  One
+// LDS-only barrier per K-step; global prefetch (two tiles ahead) stays in flight across it.
 #include "kernels.h"
 
 #include <math.h>
@@ -32,7 +35,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // SiLU on the staging path: hardware exp2 / rcp (about 1 ulp each); the extra ~2e-7 relative error is far inside
 // the stated 2e-5 UNet tolerance and keeps the transform at ~6 VALU ops per element
-static __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+static __device__ __forceinline__ float silu_f(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));   // v_exp_f32 + v_rcp_f32
+}
 
 static __device__ __forceinline__ int floor4(int s) { return (s >= 0) ? (s & ~3) : -(((-s) + 3) & ~3); }
 
@@ -57,6 +62,9 @@ struct ConvCfg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// staging transform, resolved once per K-step so the per-element code carries no mode switches
+enum { M_PLAIN = 0, M_GN = 1, M_GN_SILU = 2, M_LN = 3, M_LRELU = 4, M_GENERIC = 5 };
+
 // All per-thread state lives in one struct whose methods are force-inlined: every register array is a
 // member indexed by compile-time constants (template recursion), so nothing falls back to scratch.
 //
@@ -72,10 +80,10 @@ struct ConvKernel {
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH, TPR = Cfg::TPR, G = Cfg::G, KR = Cfg::KR;
     static constexpr int NB = Cfg::NB;
     static constexpr int P = XCH * 4 + WCH;      // commit pieces per K-step (one ds_write_b128 each)
-    static constexpr int HALF = (G / 2 > 0) ? G / 2 : 1;
 
     const ConvArgs& p;
     float* smem;
+    bool producer;
     int tid, c, h, wm, wn, b, m0, t0;
     int s_al, off, xw4, xwp, stage;
     float* cst;
@@ -91,7 +99,11 @@ struct ConvKernel {
     __device__ __forceinline__ ConvKernel(const ConvArgs& p_, float* smem_) : p(p_), smem(smem_) {}
 
     __device__ __forceinline__ void setup() {
-        tid = threadIdx.x;
+        // 8 waves: 0-3 consume (ds_read + MFMA only), 4-7 produce (global loads, normalise/activate, LDS writes).
+        // The role is made provably wave-uniform so the branch is scalar and each wave executes exactly one
+        // role's barriers.
+        producer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+        tid = threadIdx.x & 255;
         const int lane = tid & 63, wave = tid >> 6;
         c = lane & 31; h = lane >> 5;
         wm = wave / Cfg::WAVES_N; wn = wave % Cfg::WAVES_N;
@@ -142,7 +154,7 @@ struct ConvKernel {
 
     // LayerNorm over channels (reference attention.py:83,102,118): per-frame mean / rstd for this window
     __device__ __forceinline__ void colstat_prologue() {
-        for (int j = tid; j < xwp; j += 256) {
+        for (int j = threadIdx.x; j < xwp; j += 512) {
             const int s = s_al + j;
             float mean = 0.f, rstd = 0.f;
             if (s >= 0 && s < p.Tsrc) {
@@ -176,12 +188,12 @@ struct ConvKernel {
     }
 
     template <int I, int J>
-    __device__ __forceinline__ void fetch_x(int kc) {
+    __device__ __forceinline__ void fetch_x(const float* const (&rows)[4]) {
         if constexpr (I < XCH) {
             const int c4 = xc0 + I * TPR;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c4 < xw4) {
-                const float* src = rowptr(chan(kc, J));
+                const float* src = rows[J];
                 const int s = s_al + c4 * 4;
                 if (vec_ok && s >= 0 && s + 3 < p.Tsrc) {
                     v = *reinterpret_cast<const f32x4*>(src + s);
@@ -191,8 +203,8 @@ struct ConvKernel {
                 }
             }
             xr[I][J] = v;
-            if constexpr (J < 3) fetch_x<I, J + 1>(kc);
-            else fetch_x<I + 1, 0>(kc);
+            if constexpr (J < 3) fetch_x<I, J + 1>(rows);
+            else fetch_x<I + 1, 0>(rows);
         }
     }
     template <int J>
@@ -226,10 +238,9 @@ struct ConvKernel {
     }
     __device__ __forceinline__ void fetch(int kc) {
         if (p.dbg & 1) return;
-        if (xrr < KR) {
-            fetch_x<0, 0>(kc);
-            fetch_coef<0>(kc);
-        }
+        const float* const rows[4] = {rowptr(chan(kc, 0)), rowptr(chan(kc, 1)), rowptr(chan(kc, 2)), rowptr(chan(kc, 3))};
+        fetch_x<0, 0>(rows);
+        fetch_coef<0>(kc);
         fetch_w<0>(kc);
     }
 
@@ -240,17 +251,35 @@ struct ConvKernel {
     }
 
     // piece PC of the staged tile: PC < 4*XCH -> one frame of an activation chunk (transform of 4 channel rows +
-    // one ds_write_b128), else one weight chunk
-    template <int PC>
+    // one ds_write_b128), else one weight chunk.  Out-of-range frames are selected to exact zero (conv padding
+    // applies AFTER normalisation/activation in the reference), never branched around.
+    template <int PC, int MODE>
     __device__ __forceinline__ void commit_piece(float* st) {
         if (p.dbg & 2) return;
         if constexpr (PC < XCH * 4) {
             constexpr int I = PC / 4, E = PC % 4;
             const int c4 = xc0 + I * TPR;
-            if (xrr < KR && c4 < xw4) {
+            if (c4 < xw4) {
                 const int s = s_al + c4 * 4 + E;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (s >= 0 && s < p.Tsrc) {
+                const bool inb = (s >= 0 && s < p.Tsrc);
+                f32x4 v;
+                if constexpr (MODE == M_PLAIN) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = xr[I][j][E];
+                } else if constexpr (MODE == M_GN) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (xr[I][j][E] - cfa[j]) * cfb[j] + cfc[j];
+                } else if constexpr (MODE == M_GN_SILU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu_f((xr[I][j][E] - cfa[j]) * cfb[j] + cfc[j]);
+                } else if constexpr (MODE == M_LN) {
+                    const float mu = cst[c4 * 4 + E], rs = cst[xwp + c4 * 4 + E];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (xr[I][j][E] - mu) * (rs * cfa[j]) + cfb[j];
+                } else if constexpr (MODE == M_LRELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float x = xr[I][j][E]; v[j] = (x >= 0.f) ? x : x * p.slope; }
+                } else {
                     if (p.norm_mode == NORM_COLSTAT) {
                         const float mu = cst[c4 * 4 + E], rs = cst[xwp + c4 * 4 + E];
 #pragma unroll
@@ -263,6 +292,8 @@ struct ConvKernel {
                         for (int j = 0; j < 4; ++j) v[j] = act(xr[I][j][E]);
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = inb ? v[j] : 0.f;
                 *reinterpret_cast<f32x4*>(st + KT * BK * BM + (xrr * xwp + c4 * 4 + E) * 4) = v;
             }
         } else {
@@ -271,12 +302,27 @@ struct ConvKernel {
             if (q < Cfg::WCHUNKS) *reinterpret_cast<f32x4*>(st + 4 * q) = wr[J];
         }
     }
-    template <int LO, int HI>
+    template <int LO, int HI, int MODE>
     __device__ __forceinline__ void commit_range(float* st) {
         if constexpr (LO < HI) {
-            commit_piece<LO>(st);
-            commit_range<LO + 1, HI>(st);
+            commit_piece<LO, MODE>(st);
+            commit_range<LO + 1, HI, MODE>(st);
         }
+    }
+    __device__ __forceinline__ void commit_tile(float* st, int mode) {
+        switch (mode) {
+            case M_PLAIN: commit_range<0, P, M_PLAIN>(st); break;
+            case M_GN: commit_range<0, P, M_GN>(st); break;
+            case M_GN_SILU: commit_range<0, P, M_GN_SILU>(st); break;
+            case M_LN: commit_range<0, P, M_LN>(st); break;
+            case M_LRELU: commit_range<0, P, M_LRELU>(st); break;
+            default: commit_range<0, P, M_GENERIC>(st); break;
+        }
+    }
+    __device__ __forceinline__ int staging_mode() const {
+        if (p.norm_mode == NORM_NONE) return p.act_in == ACT_NONE ? M_PLAIN : (p.act_in == ACT_LRELU ? M_LRELU : M_GENERIC);
+        if (p.norm_mode == NORM_ROWCOEF) return p.act_in == ACT_NONE ? M_GN : (p.act_in == ACT_SILU ? M_GN_SILU : M_GENERIC);
+        return p.act_in == ACT_NONE ? M_LN : M_GENERIC;
     }
 
     // MFMA operands of group (tap, kq) are read from LDS NB-1 groups ahead of their use into a small register
@@ -313,25 +359,17 @@ struct ConvKernel {
         }
     }
 
-    // one K-step, fully unrolled: the first half of the MFMA groups carries the commit pieces of tile kc+1,
-    // the fetch of tile kc+2 is issued at the midpoint (its registers are free by then)
+    // consumer: all MFMA groups of one K-step, operands prefetched NB-1 groups ahead
     template <int g>
-    __device__ __forceinline__ void kstep(const float* cur, float* nxt, bool do_commit, bool do_fetch, int kc) {
+    __device__ __forceinline__ void kstep(const float* cur) {
         if constexpr (g < G) {
             if constexpr (g == 0) preload<0, NB - 1>(cur);
             if constexpr (g + NB - 1 < G) load_ops<(g + NB - 1) % NB>(cur, (g + NB - 1) / (BK / 8), (g + NB - 1) % (BK / 8));
-            if constexpr (g < HALF) {
-                constexpr int p_lo = (g * P) / HALF, p_hi = ((g + 1) * P) / HALF;
-                if (do_commit) commit_range<p_lo, p_hi>(nxt);
-            }
-            if constexpr (g == HALF || (G == 1 && g == 0)) {
-                if (do_fetch) fetch(kc + 2);
-            }
             mfma_ops<g % NB>();
             // pin the software pipeline: otherwise the machine scheduler sinks every operand read back next to its
             // MFMA (ds_read; s_waitcnt lgkmcnt(0); v_mfma) and the LDS latency is exposed once per group
             __builtin_amdgcn_sched_barrier(0);
-            kstep<g + 1>(cur, nxt, do_commit, do_fetch, kc);
+            kstep<g + 1>(cur);
         }
     }
 
@@ -347,25 +385,40 @@ struct ConvKernel {
         }
     }
 
+    // workgroup barrier that only drains LDS traffic: __syncthreads() would also wait for vmcnt(0), i.e. for
+    // the producers' global prefetch of the tile after next
+    static __device__ __forceinline__ void lds_barrier() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
     __device__ __forceinline__ void mainloop() {
         const int nk = p.Ci / BK;
-        fetch(0);
-        commit_range<0, P>(smem);
-        if (nk > 1) fetch(1);
-        __syncthreads();
-        for (int kc = 0; kc < nk; ++kc) {
-            const float* cur = smem + (kc & 1) * stage;
-            float* nxt = smem + ((kc & 1) ^ 1) * stage;
-            const bool do_commit = kc + 1 < nk, do_fetch = kc + 2 < nk;
-            if constexpr (Cfg::INTERLEAVE) {
-                kstep<0>(cur, nxt, do_commit, do_fetch, kc);
-            } else {
-                if (do_commit) commit_range<0, P>(nxt);
-                if (do_fetch) fetch(kc + 2);
-#pragma unroll 1
-                for (int tap = 0; tap < KT; ++tap) tap_groups<0>(cur, tap);
+        if (producer) {
+            const int mode = staging_mode();
+            fetch(0);
+            commit_tile(smem, mode);
+            if (nk > 1) fetch(1);
+            lds_barrier();
+            for (int kc = 0; kc < nk; ++kc) {
+                float* nxt = smem + ((kc & 1) ^ 1) * stage;
+                if (kc + 1 < nk) commit_tile(nxt, mode);     // tile kc+1: transform + LDS writes
+                if (kc + 2 < nk) fetch(kc + 2);               // tile kc+2: global loads stay in flight across the barrier
+                lds_barrier();
             }
-            __syncthreads();
+        } else {
+            lds_barrier();
+            for (int kc = 0; kc < nk; ++kc) {
+                const float* cur = smem + (kc & 1) * stage;
+                if constexpr (Cfg::INTERLEAVE) {
+                    kstep<0>(cur);
+                } else {
+#pragma unroll 1
+                    for (int tap = 0; tap < KT; ++tap) tap_groups<0>(cur, tap);
+                }
+                lds_barrier();
+            }
         }
     }
 
@@ -430,7 +483,7 @@ struct ConvKernel {
 };
 
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
-__global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(512) conv_gemm_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ConvKernel<BM, BN, KT, STRIDE, UPS, DILMAX, BK> k(p, smem);
     k.setup();
@@ -439,7 +492,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs p) {
         __syncthreads();   // cst visible before the first commit
     }
     k.mainloop();
-    k.epilogue();
+    if (!k.producer) k.epilogue();
 }
 
 static thread_local char g_cfg[96] = "";
@@ -464,7 +517,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
         attr_set = true;
     }
     snprintf(g_cfg, sizeof(g_cfg), "BM%d BN%d KT%d S%d U%d BK%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, grid.x, grid.y, lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
