@@ -79,7 +79,7 @@ struct ConvKernel {
     using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH, TPR = Cfg::TPR, G = Cfg::G, KR = Cfg::KR;
     static constexpr int NB = Cfg::NB;
-    static constexpr int P = XCH * 4 + WCH;      // commit pieces per K-step (one ds_write_b128 each)
+    static constexpr int P = XCH * 4;            // activation commit pieces per K-step (one ds_write_b128 each)
 
     const ConvArgs& p;
     float* smem;
@@ -91,7 +91,7 @@ struct ConvKernel {
     int xrr, xc0, arow;
     int bcol[TN];
     f32x4 xr[XCH][4];                  // [chunk][channel row j] = 4 frames
-    f32x4 wr[WCH];
+    __amdgpu_buffer_rsrc_t rs1, rs2;   // per-batch slabs of the two sources: out-of-slab reads return 0 (hardware range check)
     float cfa[4], cfb[4], cfc[4];      // per staged channel row: ROWCOEF mu, a, b ; COLSTAT gamma, beta
     f32x16 acc[TM][TN];
     f32x4 aop[NB][TM], bop[NB][TN];
@@ -148,8 +148,8 @@ struct ConvKernel {
         for (int i = 0; i < XCH; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) xr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) wr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1 + (long long)b * p.xb1), 0, p.C1 * p.Tsrc * 4, 0x00020000);
+        rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 + (long long)b * p.xb2), 0, p.C2 * p.Tsrc * 4, 0x00020000);
     }
 
     // LayerNorm over channels (reference attention.py:83,102,118): per-frame mean / rstd for this window
@@ -182,44 +182,41 @@ struct ConvKernel {
 
     // channel of row j (0..3) staged by this thread in K-step kc: k = 8*kq + 2*j + h'
     __device__ __forceinline__ int chan(int kc, int j) const { return kc * BK + 8 * (xrr >> 1) + 2 * j + (xrr & 1); }
-    __device__ __forceinline__ const float* rowptr(int ci) const {
-        return (ci < p.C1) ? (p.x1 + (long long)b * p.xb1 + (long long)ci * p.Tsrc)
-                           : (p.x2 + (long long)b * p.xb2 + (long long)(ci - p.C1) * p.Tsrc);
-    }
-
+    // 4 frames of channel row J for chunk I: one buffer_load_dwordx4 whose range check supplies the zeros outside the
+    // tensor; frames outside [0, Tsrc) that land in a neighbouring row are zeroed by the select in commit_piece
     template <int I, int J>
-    __device__ __forceinline__ void fetch_x(const float* const (&rows)[4]) {
+    __device__ __forceinline__ void fetch_x(int kc, bool src2) {
         if constexpr (I < XCH) {
             const int c4 = xc0 + I * TPR;
+            const int ci = chan(kc, J) - (src2 ? p.C1 : 0);
+            const int voff = (ci * p.Tsrc + s_al + c4 * 4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c4 < xw4) {
-                const float* src = rows[J];
-                const int s = s_al + c4 * 4;
-                if (vec_ok && s >= 0 && s + 3 < p.Tsrc) {
-                    v = *reinterpret_cast<const f32x4*>(src + s);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < p.Tsrc) ? src[s + e] : 0.f;
-                }
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 raw = src2 ? __builtin_amdgcn_raw_buffer_load_b128(rs2, voff, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 0, 0);
+                v = __builtin_bit_cast(f32x4, raw);
             }
             xr[I][J] = v;
-            if constexpr (J < 3) fetch_x<I, J + 1>(rows);
-            else fetch_x<I + 1, 0>(rows);
+            if constexpr (J < 3) fetch_x<I, J + 1>(kc, src2);
+            else fetch_x<I + 1, 0>(kc, src2);
         }
     }
+    // weight tile kc -> LDS stage by LDS-DMA (global_load_lds_dwordx4): a pure linear copy, no registers, no ds_write.
+    // Each wave-instruction moves 64 consecutive 16-byte chunks; the LDS base must be wave-uniform.
     template <int J>
-    __device__ __forceinline__ void fetch_w(int kc) {
+    __device__ __forceinline__ void dma_w(int kc, float* st) {
         if constexpr (J < WCH) {
-            const int q = tid + J * 256;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < Cfg::WCHUNKS) {
+            const int q0 = __builtin_amdgcn_readfirstlane(tid & ~63) + J * 256;     // first chunk of this wave
+            if (q0 < Cfg::WCHUNKS) {
+                const int q = tid + J * 256;
                 const int tap = q / (KR * BM);
                 const int rem = q - tap * (KR * BM);
                 const int rr = rem / BM, m = rem - rr * BM;
-                v = *reinterpret_cast<const f32x4*>(p.w + ((long long)(tap * (p.Ci / 4) + kc * KR + rr) * p.Mp + m0 + m) * 4);
+                const float* src = p.w + ((long long)(tap * (p.Ci / 4) + kc * KR + rr) * p.Mp + m0 + m) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(st + 4 * q0), 16, 0, 0);
             }
-            wr[J] = v;
-            fetch_w<J + 1>(kc);
+            dma_w<J + 1>(kc, st);
         }
     }
     template <int J>
@@ -238,10 +235,8 @@ struct ConvKernel {
     }
     __device__ __forceinline__ void fetch(int kc) {
         if (p.dbg & 1) return;
-        const float* const rows[4] = {rowptr(chan(kc, 0)), rowptr(chan(kc, 1)), rowptr(chan(kc, 2)), rowptr(chan(kc, 3))};
-        fetch_x<0, 0>(rows);
         fetch_coef<0>(kc);
-        fetch_w<0>(kc);
+        fetch_x<0, 0>(kc, kc * BK >= p.C1);      // C1 % BK == 0 (checked at launch): a K-step never straddles the two sources
     }
 
     __device__ __forceinline__ float act(float v) const {
@@ -296,10 +291,6 @@ struct ConvKernel {
                 for (int j = 0; j < 4; ++j) v[j] = inb ? v[j] : 0.f;
                 *reinterpret_cast<f32x4*>(st + KT * BK * BM + (xrr * xwp + c4 * 4 + E) * 4) = v;
             }
-        } else {
-            constexpr int J = PC - XCH * 4;
-            const int q = tid + J * 256;
-            if (q < Cfg::WCHUNKS) *reinterpret_cast<f32x4*>(st + 4 * q) = wr[J];
         }
     }
     template <int LO, int HI, int MODE>
@@ -397,14 +388,30 @@ struct ConvKernel {
         const int nk = p.Ci / BK;
         if (producer) {
             const int mode = staging_mode();
+            if (!(p.dbg & 1)) dma_w<0>(0, smem);
             fetch(0);
             commit_tile(smem, mode);
-            if (nk > 1) fetch(1);
+            if (nk > 1) {
+                fetch(1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XCH * 4) : "memory");   // tile-0 weight DMA landed; tile-1 loads stay in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             lds_barrier();
             for (int kc = 0; kc < nk; ++kc) {
                 float* nxt = smem + ((kc & 1) ^ 1) * stage;
-                if (kc + 1 < nk) commit_tile(nxt, mode);     // tile kc+1: transform + LDS writes
-                if (kc + 2 < nk) fetch(kc + 2);               // tile kc+2: global loads stay in flight across the barrier
+                if (kc + 1 < nk) {
+                    if (!(p.dbg & 1)) dma_w<0>(kc + 1, nxt);   // tile kc+1 weights: the DMA runs beside the transform below
+                    __builtin_amdgcn_sched_barrier(0);
+                    commit_tile(nxt, mode);                    // tile kc+1 activations: transform + LDS writes
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc + 2 < nk && !(p.dbg & 1)) {
+                    fetch(kc + 2);                             // tile kc+2 activations stay in flight across the barrier ...
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XCH * 4) : "memory");   // ... the DMA issued before them must have landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 lds_barrier();
             }
         } else {
