@@ -28,6 +28,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace lds {
 
@@ -57,7 +58,12 @@ struct ConvCfg {
     static constexpr int G = KT * BK / 8;                  // MFMA groups per K-step: one (tap, kq) = 4 k-pairs
     static constexpr bool INTERLEAVE = (KT <= 3);          // fully unrolled K-step with commit pieces between MFMA groups
     static constexpr int NB = (TM * TN >= 4) ? 2 : 3;      // operand ring depth (groups)
-    static constexpr size_t lds_bytes(int xw4) { return (size_t)(2 * (KT * BK * BM + BK * xw4 * 4) + 2 * xw4 * 4) * sizeof(float); }
+    // independent accumulator chains per output tile: a single dependent chain of v_mfma_f32_32x32x2_f32 issued only
+    // every ~106 cycles in the consumer-only ablation (64 is the pipe rate), two interleaved chains hide the
+    // accumulator read-after-write gap; the chains are summed once in the epilogue
+    static constexpr int NACC = (TM * TN >= 2) ? 1 : 2;
+    static constexpr int NST = 2;                          // LDS ring stages (3 measured slower here: one workgroup per CU instead of two)
+    static constexpr size_t lds_bytes(int xw4) { return (size_t)(NST * (KT * BK * BM + BK * xw4 * 4) + 2 * xw4 * 4) * sizeof(float); }
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,7 +84,7 @@ template <int BM, int BN, int KT, int STRIDE, bool UPS, int DILMAX, int BK>
 struct ConvKernel {
     using Cfg = ConvCfg<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, XCH = Cfg::XCH, WCH = Cfg::WCH, TPR = Cfg::TPR, G = Cfg::G, KR = Cfg::KR;
-    static constexpr int NB = Cfg::NB;
+    static constexpr int NB = Cfg::NB, NACC = Cfg::NACC;
     static constexpr int P = XCH * 4;            // activation commit pieces per K-step (one ds_write_b128 each)
 
     const ConvArgs& p;
@@ -93,7 +99,7 @@ struct ConvKernel {
     f32x4 xr[XCH][4];                  // [chunk][channel row j] = 4 frames
     __amdgpu_buffer_rsrc_t rs1, rs2;   // per-batch slabs of the two sources: out-of-slab reads return 0 (hardware range check)
     float cfa[4], cfb[4], cfc[4];      // per staged channel row: ROWCOEF mu, a, b ; COLSTAT gamma, beta
-    f32x16 acc[TM][TN];
+    f32x16 acc[NACC][TM][TN];
     f32x4 aop[NB][TM], bop[NB][TN];
 
     __device__ __forceinline__ ConvKernel(const ConvArgs& p_, float* smem_) : p(p_), smem(smem_) {}
@@ -126,7 +132,7 @@ struct ConvKernel {
         xw4 = (width + 3) >> 2;
         xwp = xw4 * 4;
         stage = KT * BK * BM + BK * xwp;   // floats per LDS stage
-        cst = smem + 2 * stage;            // [2][xwp] LayerNorm mean / rstd of the window's frames
+        cst = smem + Cfg::NST * stage;     // [2][xwp] LayerNorm mean / rstd of the window's frames
         vec_ok = ((p.Tsrc & 3) == 0);
         xrr = tid / TPR;                   // staged k-row (kq*2 + h') of this thread, chunks xc0, xc0+TPR, ...
         xc0 = tid - xrr * TPR;
@@ -137,11 +143,13 @@ struct ConvKernel {
             bcol[j] = UPS ? nl : (off + nl * STRIDE);
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int a = 0; a < NACC; ++a)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { cfa[j] = 0.f; cfb[j] = 1.f; cfc[j] = 0.f; }
 #pragma unroll
@@ -219,22 +227,20 @@ struct ConvKernel {
             dma_w<J + 1>(kc, st);
         }
     }
+    // per-row coefficients: ALWAYS one float4 load per staged channel row (so the producers' counted vmcnt is the same
+    // in every mode): GroupNorm {mu, a, b, -} at coef[b][ci]; LayerNorm {gamma, beta, -, -} at coef[ci]; otherwise a
+    // dummy read of coef[0] (the host passes a valid pointer in every mode)
     template <int J>
     __device__ __forceinline__ void fetch_coef(int kc) {
         if constexpr (J < 4) {
-            float a0 = 0.f, a1 = 1.f, a2 = 0.f;
-            if (p.norm_mode == NORM_ROWCOEF) {
-                const float4 cf = p.coef[(long long)b * p.Ci + chan(kc, J)];
-                a0 = cf.x; a1 = cf.y; a2 = cf.z;
-            } else if (p.norm_mode == NORM_COLSTAT) {
-                a0 = p.gamma[chan(kc, J)]; a1 = p.beta[chan(kc, J)];
-            }
-            cfa[J] = a0; cfb[J] = a1; cfc[J] = a2;
+            const long long idx = (p.norm_mode == NORM_ROWCOEF) ? ((long long)b * p.Ci + chan(kc, J))
+                                                               : ((p.norm_mode == NORM_COLSTAT) ? (long long)chan(kc, J) : 0ll);
+            const float4 cf = p.coef[idx];
+            cfa[J] = cf.x; cfb[J] = cf.y; cfc[J] = cf.z;
             fetch_coef<J + 1>(kc);
         }
     }
     __device__ __forceinline__ void fetch(int kc) {
-        if (p.dbg & 1) return;
         fetch_coef<0>(kc);
         fetch_x<0, 0>(kc, kc * BK >= p.C1);      // C1 % BK == 0 (checked at launch): a K-step never straddles the two sources
     }
@@ -339,7 +345,7 @@ struct ConvKernel {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[SLOT][i][jj], bop[SLOT][j][jj], acc[i][j], 0, 0, 0);
+                    acc[jj % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[SLOT][i][jj], bop[SLOT][j][jj], acc[jj % NACC][i][j], 0, 0, 0);
     }
 
     template <int g0, int g1>
@@ -385,39 +391,56 @@ struct ConvKernel {
     }
 
     __device__ __forceinline__ void mainloop() {
+        constexpr int NST = Cfg::NST;
+        constexpr int AHEAD = NST - 1;                // tiles staged ahead of the one being consumed
+        constexpr int INFLIGHT = WCH + 4 + XCH * 4;   // VMEM ops of one producer iteration: weight DMA batch + coefficient/activation loads
         const int nk = p.Ci / BK;
         if (producer) {
             const int mode = staging_mode();
-            if (!(p.dbg & 1)) dma_w<0>(0, smem);
+            // prologue: tiles 0..AHEAD-1 staged, tile AHEAD's activations in registers
             fetch(0);
-            commit_tile(smem, mode);
-            if (nk > 1) {
-                fetch(1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XCH * 4) : "memory");   // tile-0 weight DMA landed; tile-1 loads stay in flight
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            lds_barrier();
-            for (int kc = 0; kc < nk; ++kc) {
-                float* nxt = smem + ((kc & 1) ^ 1) * stage;
-                if (kc + 1 < nk) {
-                    if (!(p.dbg & 1)) dma_w<0>(kc + 1, nxt);   // tile kc+1 weights: the DMA runs beside the transform below
-                    __builtin_amdgcn_sched_barrier(0);
-                    commit_tile(nxt, mode);                    // tile kc+1 activations: transform + LDS writes
-                }
+            for (int t = 0; t < AHEAD && t < nk; ++t) {
+                commit_tile(smem + t * stage, mode);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kc + 2 < nk && !(p.dbg & 1)) {
-                    fetch(kc + 2);                             // tile kc+2 activations stay in flight across the barrier ...
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XCH * 4) : "memory");   // ... the DMA issued before them must have landed
+                dma_w<0>(t, smem + t * stage);
+                if (t + 1 < nk) fetch(t + 1);
+            }
+            if (nk > AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XCH * 4) : "memory");   // every DMA landed, newest loads in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            int sn = (AHEAD == NST) ? 0 : AHEAD;            // stage of tile kc+AHEAD
+            for (int kc = 0; kc < nk; ++kc) {
+                float* nxt = smem + sn * stage;
+                if (kc + AHEAD < nk) {
+                    // activations of tile kc+AHEAD (loaded one K-step ago): transform + LDS writes.  Done BEFORE issuing the
+                    // DMA: hipcc drains vmcnt(0) at the first use of a register load while an LDS-DMA is in flight.
+                    commit_tile(nxt, mode);
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_w<0>(kc + AHEAD, nxt);               // weights of tile kc+AHEAD
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kc + AHEAD + 1 < nk) {
+                        fetch(kc + AHEAD + 1);
+                        if constexpr (AHEAD >= 2) {
+                            // the weight DMA issued one K-step ago must have landed; this K-step's DMA + loads stay in flight
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XCH * 4) : "memory");   // this K-step's DMA landed
+                        }
+                    } else {
+                        if constexpr (AHEAD >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 lds_barrier();
+                sn = (sn + 1 == NST) ? 0 : sn + 1;
             }
         } else {
             lds_barrier();
+            int sc = 0;
             for (int kc = 0; kc < nk; ++kc) {
-                const float* cur = smem + (kc & 1) * stage;
+                const float* cur = smem + sc * stage;
                 if constexpr (Cfg::INTERLEAVE) {
                     kstep<0>(cur);
                 } else {
@@ -425,6 +448,7 @@ struct ConvKernel {
                     for (int tap = 0; tap < KT; ++tap) tap_groups<0>(cur, tap);
                 }
                 lds_barrier();
+                sc = (sc + 1 == NST) ? 0 : sc + 1;
             }
         }
     }
@@ -442,10 +466,10 @@ struct ConvKernel {
                 for (int r = 0; r < 16; ++r) {
                     const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int m = m0 + wm * TM * 32 + i * 32 + rloc;      // packed row
-                    float v = acc[i][j][r];
+                    float v = (NACC == 2) ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] : acc[0][i][j][r];
                     int orow;
                     if (geglu) {
-                        float g = acc[TM - 1][j][r];
+                        float g = acc[0][TM - 1][j][r];
                         if (p.bias) { v += p.bias[m]; g += p.bias[m + 32]; }
                         v = v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
                         orow = (m0 + wm * 64) / 2 + rloc;
@@ -558,8 +582,9 @@ hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const bool wide = a.dil > 1;
     if (a.dil > 5) return hipErrorInvalidValue;
-    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0);
-    const bool k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
+    static const int bk_max = getenv("LDS_BK") ? atoi(getenv("LDS_BK")) : 64;    // experiments only
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0) && bk_max >= 32;
+    const bool k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0) && bk_max >= 64;
     switch (tile) {
         case 128128:
             if (key == 110 && k32) LDS_CASE(128, 128, 1, 1, false, 1, 32);
@@ -573,6 +598,7 @@ hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
             break;
         case 64064:
             if (key == 110 && k64) LDS_CASE(64, 64, 1, 1, false, 1, 64);
+            if (key == 110 && k32) LDS_CASE(64, 64, 1, 1, false, 1, 32);
             if (key == 110) LDS_CASE(64, 64, 1, 1, false, 1, 16);
             if (key == 210) LDS_CASE(64, 64, 2, 1, false, 1, 16);
             if (key == 310 && !wide && k32) LDS_CASE(64, 64, 3, 1, false, 1, 32);

@@ -28,9 +28,9 @@ struct ConvArgs {
     int Mp, Co, Ci, KT, stride, dil, pad, ups;
     // normalise-on-load
     int norm_mode;
-    const float4* coef;      // NORM_ROWCOEF: [B][Ci] {mu, a, b, -}: v = (x-mu)*a + b
+    const float4* coef;      // NORM_ROWCOEF: [B][Ci] {mu, a, b, -}: v = (x-mu)*a + b; NORM_COLSTAT: [Ci] {gamma, beta, -, -};
+                             // NORM_NONE: any valid device pointer (read, ignored)
     const float* cmean; const float* crstd;   // NORM_COLSTAT: [B][Tsrc]
-    const float* gamma; const float* beta;    // NORM_COLSTAT: [Ci]
     const float2* lnpart; int ln_np; float ln_eps;   // NORM_COLSTAT alternative to cmean/crstd: [B][ln_np][Tsrc] (mean, M2)
                                                      // partials over 32 channels each, combined in the kernel prologue
     int act_in; float slope;

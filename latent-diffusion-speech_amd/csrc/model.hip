@@ -215,7 +215,7 @@ struct Src {
 struct ConvOpt {
     int stride = 1, pad = 0, dil = 1, ups = 0;
     int norm_mode = NORM_NONE; const float4* coef = nullptr;
-    const float* cmean = nullptr; const float* crstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    const float* cmean = nullptr; const float* crstd = nullptr;
     const float2* lnpart = nullptr; int ln_np = 0; float ln_eps = 1e-5f; float2* lnpart_out = nullptr;
     int act_in = ACT_NONE; float slope = 0.f;
     const float* bias_bc = nullptr; const float* res = nullptr;
@@ -232,7 +232,7 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.xb1 = (long long)s.C1 * s.Tsrc; a.xb2 = (long long)s.C2 * s.Tsrc;
     a.w = W.w; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
     a.stride = o.stride; a.dil = o.dil; a.pad = o.pad; a.ups = o.ups;
-    a.norm_mode = o.norm_mode; a.coef = o.coef; a.cmean = o.cmean; a.crstd = o.crstd; a.gamma = o.gamma; a.beta = o.beta;
+    a.norm_mode = o.norm_mode; a.coef = o.coef ? o.coef : (const float4*)W.w; a.cmean = o.cmean; a.crstd = o.crstd;
     a.lnpart = o.lnpart; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.lnpart_out = o.lnpart_out;
     a.act_in = o.act_in; a.slope = o.slope;
     a.bias = W.bias; a.bias_bc = o.bias_bc; a.res = o.res; a.epi = o.epi; a.accum = o.accum; a.out_div = o.out_div;
@@ -278,7 +278,7 @@ struct ResnetW {
 struct TfmW {
     int C = 0;
     float *gn_g = nullptr, *gn_b = nullptr;
-    float *ln_g[3] = {nullptr, nullptr, nullptr}, *ln_b[3] = {nullptr, nullptr, nullptr};
+    float4* ln_gb[3] = {nullptr, nullptr, nullptr};   // LayerNorm {gamma, beta, 0, 0} per channel
     ConvW proj_in, proj_out, qkv[2], o[2], ff1, ff2;
 };
 struct DownBlk { std::vector<ResnetW> res; std::vector<TfmW> att; bool has_down = false; ConvW down; int ch = 0; };
@@ -350,9 +350,13 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
     const std::string b = p + "transformer_blocks.0.";
     for (int i = 0; i < 3; ++i) {
         const std::string n = b + "norm" + std::to_string(i + 1);
-        t.ln_g[i] = up_vec(o, T.get(n + ".weight", C), C);
-        t.ln_b[i] = up_vec(o, T.get(n + ".bias", C), C);
-        if (!t.ln_g[i] || !t.ln_b[i]) return false;
+        const float* g = T.get(n + ".weight", C);
+        const float* be = T.get(n + ".bias", C);
+        if (!g || !be) return false;
+        std::vector<float> gb((size_t)4 * C, 0.f);
+        for (int c = 0; c < C; ++c) { gb[4 * c] = g[c]; gb[4 * c + 1] = be[c]; }
+        t.ln_gb[i] = (float4*)o.upload(gb);
+        if (!t.ln_gb[i]) return false;
     }
     for (int i = 0; i < 2; ++i) {
         const std::string a = b + "attn" + std::to_string(i + 1) + ".";
@@ -610,7 +614,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     for (int a = 0; a < 2; ++a) {
         Src sh{h, C, nullptr, 0, T};
         ConvOpt oq;
-        oq.norm_mode = NORM_COLSTAT; oq.lnpart = w.lnp; oq.ln_np = C / 32; oq.ln_eps = 1e-5f; oq.gamma = t.ln_g[a]; oq.beta = t.ln_b[a];
+        oq.norm_mode = NORM_COLSTAT; oq.lnpart = w.lnp; oq.ln_np = C / 32; oq.ln_eps = 1e-5f; oq.coef = t.ln_gb[a];
         LDS_TRY(run_conv(t.qkv[a], sh, oq, w.qkv, B, st));
         { ProfScope ps(st, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T); HIP_TRY(launch_attention(w.qkv, w.att, B, C, T, u->heads, st)); }
         Src sa{w.att, C, nullptr, 0, T};
@@ -621,7 +625,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     }
     Src sh{h, C, nullptr, 0, T};
     ConvOpt of;
-    of.norm_mode = NORM_COLSTAT; of.lnpart = w.lnp; of.ln_np = C / 32; of.ln_eps = 1e-5f; of.gamma = t.ln_g[2]; of.beta = t.ln_b[2];
+    of.norm_mode = NORM_COLSTAT; of.lnpart = w.lnp; of.ln_np = C / 32; of.ln_eps = 1e-5f; of.coef = t.ln_gb[2];
     of.epi = EPI_GEGLU;
     LDS_TRY(run_conv(t.ff1, sh, of, w.ff, B, st));
     Src sf{w.ff, 4 * C, nullptr, 0, T};
@@ -1131,7 +1135,11 @@ static int test_conv_impl(const lds_conv_test* a, float* out, int B, int iters, 
     } else if (a->norm_mode == NORM_COLSTAT) {
         if (a->C2) return fail(LDS_EINVAL, "LayerNorm test takes a single source");
         HIP_TRY(launch_ln_stats(a->x1, Ci, T, a->eps, lm, lr, B, st));
-        o.norm_mode = NORM_COLSTAT; o.cmean = lm; o.crstd = lr; o.gamma = g; o.beta = be;
+        std::vector<float> gb((size_t)4 * Ci, 0.f);
+        for (int c = 0; c < Ci; ++c) { gb[4 * c] = a->gamma[c]; gb[4 * c + 1] = a->beta[c]; }
+        float4* dgb = (float4*)own.upload(gb);
+        if (!dgb) return fail(LDS_ENOMEM, "test conv: upload failed");
+        o.norm_mode = NORM_COLSTAT; o.cmean = lm; o.crstd = lr; o.coef = dgb;
     }
     Src s{a->x1, a->C1, a->x2, a->C2, T};
     int r = run_conv(W, s, o, out, B, st);
@@ -1175,8 +1183,10 @@ extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w
     Owner own;
     ConvW W1, W2;
     if (!pack_conv(own, w1, nullptr, C, C, 1, W1) || !pack_conv(own, w2, nullptr, Co, C, 1, W2)) return fail(LDS_ENOMEM, "upload failed");
-    float* g = up_vec(own, gamma, C);
-    float* be = up_vec(own, beta, C);
+    std::vector<float> gbv((size_t)4 * C, 0.f);
+    for (int c = 0; c < C; ++c) { gbv[4 * c] = gamma[c]; gbv[4 * c + 1] = beta[c]; }
+    float4* dgb = (float4*)own.upload(gbv);
+    if (!dgb) return fail(LDS_ENOMEM, "upload failed");
     void* part = nullptr;
     HIP_TRY(hipMalloc(&part, (size_t)B * (C / 32) * T * sizeof(float2)));
     own.ptrs.push_back(part);
@@ -1186,7 +1196,7 @@ extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w
     LDS_TRY(run_conv(W1, s1, o1, mid, B, st));
     Src s2{mid, C, nullptr, 0, T};
     ConvOpt o2;
-    o2.norm_mode = NORM_COLSTAT; o2.lnpart = (const float2*)part; o2.ln_np = C / 32; o2.ln_eps = eps; o2.gamma = g; o2.beta = be;
+    o2.norm_mode = NORM_COLSTAT; o2.lnpart = (const float2*)part; o2.ln_np = C / 32; o2.ln_eps = eps; o2.coef = dgb;
     int r = run_conv(W2, s2, o2, out, B, st);
     HIP_TRY(hipStreamSynchronize(st));
     return r;
