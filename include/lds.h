@@ -160,6 +160,26 @@ int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream);
 int lds_bench_conv(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
                    void* stream);
 /* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
+/* ---- the UNet's K4P path, one op at a time (plain tensors in/out; layout conversion happens on the device) ---- */
+typedef struct {
+    const float* x1; const float* x2;   /* dev inputs [B,C1,T], [B,C2,T] (x2 may be NULL)                 */
+    int C1, C2, T;
+    const float* w; const float* bias;  /* host, reference layout [Co, C1+C2, K] / [Co]                   */
+    int Co, K, stride, pad, ups;
+    const float* res;                   /* dev [B,Cout,To] or NULL                                        */
+    int epilogue;                       /* 0 none, 1 GEGLU                                                */
+    int plain_out;                      /* 1: the kernel writes frame-major output directly               */
+    int v_split;                        /* 1: last third of the output channels stored frame-major (QKV)  */
+    int cfg;                            /* 0 auto, else BM*1000000 + BN*1000 + BK*10 + NST                */
+} lds_dconv_test;
+int lds_test_dconv(const lds_dconv_test* a, float* out, float* lnpart, int B, void* stream);
+int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
+                    void* stream);
+int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                      const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
+int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
+                          float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
+int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
 /* mid = w1*x (1x1, [C,C]); out = w2 * LayerNorm_C(mid) (1x1, [Co,C]); statistics travel as epilogue partials */
 int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
                       float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);

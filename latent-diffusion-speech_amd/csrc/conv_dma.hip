@@ -1,0 +1,376 @@
+// DMA-fed, VALU-free implicit-GEMM convolution for the UNet (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Why this kernel exists.  On gfx950 the fp32 MFMA executes on the SIMD's vector ALU: measured with
+// tools/ubench/mfma_valu_coexec.hip, an MFMA-only wave and a VALU-only wave on one SIMD take the SUM of
+// their times (154.7 TFLOP/s alone; every co-resident FMA / exp / integer instruction adds its full issue
+// time).  So in an fp32 GEMM every VALU instruction -- address arithmetic, normalisation, SiLU, bounds
+// selects, register->LDS staging -- is paid in matrix throughput, whichever wave issues it.  This kernel
+// therefore contains no per-element VALU work at all:
+//   * activations live in HBM in the "K4P" layout (k4p.h): [B][C/8][2][T+2][4], channel 8q+2j+h at element j of
+//     row (q,h), one zero pad frame on both sides.  A k-interleaved row is byte-for-byte the LDS image the MFMA
+//     wants (one ds_read_b128 = the B operands of four consecutive MFMAs), and the pad frames ARE the
+//     convolution's zero padding, so a tile is a plain linear copy;
+//   * both operand tiles are moved HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+//     ds_write, loop-invariant per-lane offsets, one scalar pointer bump per K-step;
+//   * normalisation + activation are applied ONCE per tensor by the small memory-bound kernels in k4p_ops.hip
+//     (instead of once per output-channel block inside the GEMM);
+//   * the k3 taps are shifted reads of the same LDS window; skip-concat = second source pointer selected per
+//     K-step; nearest-2x upsample = (frame >> 1) in the operand address; stride 2 = operand stride.
+// Pipeline: NST-stage LDS ring, every wave issues 1/4 of each tile's DMA NST-1 tiles ahead, waits with a COUNTED
+// vmcnt for its share of the current tile, then one s_barrier per K-step (no vmcnt(0) drain).
+#include "k4p.h"
+#include "kernels.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace lds {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+struct DmaCfg {
+    static constexpr int WAVES_M = 2, WAVES_N = 2;
+    static constexpr int TM = BM / 64, TN = BN / 64;
+    static constexpr int KR = BK / 4;                                   // staged k-rows per K-step
+    static constexpr int XW = UPS ? (BN / 2 + 2) : ((BN - 1) * STRIDE + KT);   // window entries (frames) per k-row
+    static constexpr int WI = KT * KR * BM / 64;                        // weight DMA wave-instructions per tile
+    static constexpr int WPW = WI / 4;                                  // ... per wave
+    static constexpr int RPW = KR / 4;                                  // activation k-rows staged by each wave
+    static constexpr int NXI = (RPW * XW + 63) / 64;                    // activation DMA wave-instructions per wave
+    static constexpr int PER_TILE = WPW + NXI;                          // VMEM ops per wave per tile
+    static constexpr int G = KT * BK / 8;                               // MFMA groups per K-step (4 k-pairs each)
+    static constexpr int NB = (TM * TN >= 4) ? 2 : 3;                   // operand ring depth
+    static constexpr int NACC = (TM * TN >= 2) ? 1 : 2;                 // independent accumulator chains per tile
+    static constexpr int STAGE = KT * BK * BM + KR * XW * 4;            // floats
+    static constexpr size_t LDS_BYTES = (size_t)NST * STAGE * sizeof(float);
+    // workgroups per CU allowed by LDS = waves per SIMD to ask the register allocator for (each workgroup puts one wave on each SIMD)
+    static constexpr int OCC_LDS = (int)((160 * 1024) / LDS_BYTES);
+    static constexpr int OCC = (TM * TN >= 4) ? (OCC_LDS < 2 ? OCC_LDS : 2) : (OCC_LDS < 4 ? (OCC_LDS < 1 ? 1 : OCC_LDS) : 4);
+    static_assert(WI % 4 == 0 && KR % 4 == 0, "tile does not split evenly over 4 waves");
+};
+
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+struct DmaKernel {
+    using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    static constexpr int TM = Cfg::TM, TN = Cfg::TN, KR = Cfg::KR, XW = Cfg::XW, WPW = Cfg::WPW, RPW = Cfg::RPW, NXI = Cfg::NXI;
+    static constexpr int G = Cfg::G, NB = Cfg::NB, NACC = Cfg::NACC, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE;
+
+    const DmaConvArgs& p;
+    float* smem;
+    int lane, wave, c, h, wm, wn, b, m0, t0;
+    int woff[WPW];            // per-lane float offsets of this wave's weight chunks (loop invariant)
+    int xoff[NXI];            // per-lane float offsets of this wave's activation chunks inside a source slab
+    bool xact[NXI];
+    int arow;
+    int bcol[TN];
+    f32x16 acc[NACC][TM][TN];
+    f32x4 aop[NB][TM], bop[NB][TN];
+
+    __device__ __forceinline__ DmaKernel(const DmaConvArgs& p_, float* s_) : p(p_), smem(s_) {}
+
+    __device__ __forceinline__ void setup() {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        c = lane & 31; h = lane >> 5;
+        wm = wave >> 1; wn = wave & 1;
+        const int nMb = p.Mp / BM;
+        const int mb = blockIdx.x % nMb;          // M fastest: neighbouring blocks share the activation tile (L2)
+        const int nb = blockIdx.x / nMb;
+        b = blockIdx.y;
+        m0 = mb * BM; t0 = nb * BN;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int q = (wave + 4 * i) * 64 + lane;           // chunk = (tap, k-row, m)
+            const int tap = q / (KR * BM);
+            const int rem = q - tap * (KR * BM);
+            const int rr = rem / BM, m = rem - rr * BM;
+            woff[i] = ((tap * (p.Ci / 4) + rr) * p.Mp + m0 + m) * 4;
+        }
+        const int Tp = p.Tsrc + 2;
+        const int e0 = UPS ? (((t0 - 1) >> 1) + 1) : (t0 * STRIDE - p.pad + 1);   // first window entry (pad frame = entry 0)
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int qq = i * 64 + lane;
+            const int rl = qq / XW, col = qq - rl * XW;
+            xact[i] = qq < RPW * XW;
+            xoff[i] = ((wave * RPW + rl) * Tp + e0 + col) * 4;
+        }
+        arow = wm * TM * 32 + c;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+    }
+
+    // tile kc -> LDS stage `st`: this wave's share of the weight chunks and of the activation window
+    __device__ __forceinline__ void issue_tile(int kc, float* st) {
+        const float* wb = p.w + (long long)kc * KR * p.Mp * 4;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + woff[i]),
+                                             (__attribute__((address_space(3))) void*)(st + ((wave + 4 * i) * 64) * 4), 16, 0, 0);
+        const int k0 = kc * BK;
+        const bool s2 = k0 >= p.C1;                              // C1 % BK == 0: a K-step reads one source only
+        const int Tp = p.Tsrc + 2;
+        const float* xb = s2 ? (p.x2 + ((long long)b * p.C2 + (k0 - p.C1)) * Tp) : (p.x1 + ((long long)b * p.C1 + k0) * Tp);
+        float* xs = st + KT * BK * BM + wave * RPW * XW * 4;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i)
+            if (xact[i])
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
+                                                 (__attribute__((address_space(3))) void*)(xs + i * 64 * 4), 16, 0, 0);
+    }
+
+    template <int SLOT>
+    __device__ __forceinline__ void load_ops(const float* st, int tap, int kq) {
+        const float* wt = st + ((tap * KR + kq * 2 + h) * BM + arow) * 4;
+        const float* xs = st + KT * BK * BM + (kq * 2 + h) * XW * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) aop[SLOT][i] = *reinterpret_cast<const f32x4*>(wt + i * 32 * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - ((t0 - 1) >> 1)) : (bcol[j] * STRIDE + tap);
+            bop[SLOT][j] = *reinterpret_cast<const f32x4*>(xs + col * 4);
+        }
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void mfma_ops() {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[jj % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[SLOT][i][jj], bop[SLOT][j][jj], acc[jj % NACC][i][j], 0, 0, 0);
+    }
+    template <int g0, int g1>
+    __device__ __forceinline__ void preload(const float* cur) {
+        if constexpr (g0 < g1 && g0 < G) {
+            load_ops<g0 % NB>(cur, g0 / (BK / 8), g0 % (BK / 8));
+            preload<g0 + 1, g1>(cur);
+        }
+    }
+    template <int g>
+    __device__ __forceinline__ void kstep(const float* cur) {
+        if constexpr (g < G) {
+            if constexpr (g == 0) preload<0, NB - 1>(cur);
+            if constexpr (g + NB - 1 < G) load_ops<(g + NB - 1) % NB>(cur, (g + NB - 1) / (BK / 8), (g + NB - 1) % (BK / 8));
+            mfma_ops<g % NB>();
+            __builtin_amdgcn_sched_barrier(0);     // keep the operand reads NB-1 groups ahead of their MFMAs
+            kstep<g + 1>(cur);
+        }
+    }
+
+    __device__ __forceinline__ void mainloop() {
+        constexpr int AHEAD = NST - 1;
+        const int nk = p.Ci / BK;
+        for (int t = 0; t < AHEAD && t < nk; ++t) issue_tile(t, smem + t * STAGE);
+        int sc = 0, sn = AHEAD % NST;
+        for (int kc = 0; kc < nk; ++kc) {
+            // this wave's share of tile kc has landed when at most the younger tiles' DMAs are outstanding
+            const int younger = (nk - 1 - kc < AHEAD - 1) ? (nk - 1 - kc) : (AHEAD - 1);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave's share landed; every wave is done with the stage refilled below
+            asm volatile("" ::: "memory");
+            if (kc + AHEAD < nk) issue_tile(kc + AHEAD, smem + sn * STAGE);
+            kstep<0>(smem + sc * STAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            sc = (sc + 1 == NST) ? 0 : sc + 1;
+            sn = (sn + 1 == NST) ? 0 : sn + 1;
+        }
+    }
+
+    // value of output register r of tile (i, j) after bias / GEGLU
+    __device__ __forceinline__ float outval(int i, int j, int r, bool geglu) const {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // packed weight row
+        float v = (NACC == 2) ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] : acc[0][i][j][r];
+        if (geglu) {
+            float g = acc[0][TM - 1][j][r];
+            if (p.bias) { v += p.bias[m]; g += p.bias[m + 32]; }
+            v = v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+        } else if (p.bias) {
+            v += p.bias[m];
+        }
+        return v;
+    }
+
+    // frame-major store of one 32x32 tile: out[b][co][n], co = c0 + local row
+    __device__ __forceinline__ void store_plain(float* base, int Cn, int c0, int i, int j, int n, bool geglu) {
+        if (n >= p.To) return;
+        float* ob = base + ((long long)b * Cn + c0) * p.To + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (c0 + rl < Cn) ob[rl * p.To] = outval(i, j, r, geglu);
+        }
+    }
+
+    // K4P store of one 32x32 tile (+ residual, + pad frames, + LayerNorm partials).  Registers (4g+hh, 4g+2+hh) of this
+    // lane are elements (2h, 2h+1) of row (q = tile0/8 + g, hh): two 8-byte stores per 8-channel block; the two lane
+    // halves together fill the 16-byte entry, and consecutive lanes are consecutive frames.
+    __device__ __forceinline__ void store_k4p(int tile0, int i, int j, int n, bool geglu) {
+        const int Tpo = p.To + 2;
+        const int Ck = (p.plain_from < p.Cout) ? p.plain_from : p.Cout;
+        float* ob = p.out + (long long)b * Ck * Tpo;
+        const float* rb = p.res ? p.res + (long long)b * Ck * Tpo : nullptr;
+        const bool ok = n < p.To;
+        int off = (((tile0 >> 3) * 2) * Tpo + n + 1) * 4 + 2 * h;       // row (q0, hh=0); +Tpo*4 per row
+        float s1 = 0.f, vals[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x2 v = {outval(i, j, 4 * g + hh, geglu), outval(i, j, 4 * g + 2 + hh, geglu)};
+                if (ok) {
+                    if (rb) v += *reinterpret_cast<const f32x2*>(rb + off);
+                    *reinterpret_cast<f32x2*>(ob + off) = v;
+                    if (n == 0) *reinterpret_cast<f32x2*>(ob + off - 4) = f32x2{0.f, 0.f};          // left pad frame
+                    if (n == p.To - 1) *reinterpret_cast<f32x2*>(ob + off + 4) = f32x2{0.f, 0.f};   // right pad frame
+                }
+                vals[4 * g + hh] = v[0]; vals[4 * g + 2 + hh] = v[1];
+                s1 += v[0] + v[1];
+                off += Tpo * 4;
+            }
+        }
+        if (p.lnpart_out) {
+            // per-frame (mean, M2) over this tile's 32 channels -> LayerNorm partials (combined by ln_apply)
+            const float m16 = s1 * (1.0f / 16.0f);
+            float qv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = vals[r] - m16; qv += d * d; }
+            const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(qv, 32, 64);
+            const float d = mo - m16;
+            if (h == 0 && ok)
+                p.lnpart_out[((long long)b * (Ck >> 5) + (tile0 >> 5)) * p.To + n] = make_float2(0.5f * (m16 + mo), (qv + qo) + d * d * 8.0f);
+        }
+    }
+
+    __device__ __forceinline__ void epilogue() {
+        const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (geglu && i == 1) break;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = t0 + wn * TN * 32 + j * 32 + c;
+                const int tile0 = geglu ? (m0 + wm * 64) / 2 : (m0 + wm * TM * 32 + i * 32);   // first output channel of this tile
+                if (p.out_plain) store_plain(p.out, p.Cout, tile0, i, j, n, geglu);
+                else if (tile0 >= p.plain_from) store_plain(p.out2, p.Cout - p.plain_from, tile0 - p.plain_from, i, j, n, geglu);
+                else if (tile0 < p.Cout) store_k4p(tile0, i, j, n, geglu);
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+__global__ void __launch_bounds__(256, (DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>::OCC)) conv_dma_kernel(const DmaConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST> k(p, smem);
+    k.setup();
+    k.mainloop();
+    k.epilogue();
+}
+
+static thread_local char g_dcfg[96] = "";
+const char* conv_dma_last_config() { return g_dcfg; }
+
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
+    using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    const int nN = (a.To + BN - 1) / BN;
+    dim3 grid((a.Mp / BM) * nN, a.B);
+    auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x,
+             grid.y, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+#define DCASE(BM, BN, KT, ST, UP, BK, NS) return launch_dma_cfg<BM, BN, KT, ST, UP, BK, NS>(a, s)
+
+// cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
+hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
+    if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || (a.pad != 0 && a.pad != 1)) return hipErrorInvalidValue;
+    if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
+    static const int env_cfg = getenv("LDS_DMA_CFG") ? atoi(getenv("LDS_DMA_CFG")) : 0;     // experiments only
+    if (cfg == 0) cfg = env_cfg;
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
+    auto blocks = [&](int bm, int bn) -> long long { return (a.Mp % bm) ? -1 : (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B; };
+    int bm, bn, bk, nst;
+    if (cfg) {
+        bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
+    } else {
+        if (a.epi == EPI_GEGLU || (a.stride == 1 && !a.ups && blocks(128, 128) >= 512)) { bm = 128; bn = 128; }
+        else { bm = 64; bn = 64; }
+        if (a.epi == EPI_GEGLU && blocks(128, 128) < 384) bn = 64;
+        bk = (a.KT == 1) ? (bm == 128 ? 32 : 64) : (bm == 128 ? 16 : 32);
+        nst = 2;
+    }
+    if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
+    if (a.Mp % bm) return hipErrorInvalidValue;
+    if ((bk == 64 && !k64) || (bk == 32 && !k32)) bk = 16;
+    const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
+    const int tk = bm * 1000 + bn;
+    if (key == 110) {
+        if (tk == 64064) {
+            if (bk == 64 && nst == 2) DCASE(64, 64, 1, 1, false, 64, 2);
+            if (bk == 64 && nst == 3) DCASE(64, 64, 1, 1, false, 64, 3);
+            if (bk == 32 && nst == 2) DCASE(64, 64, 1, 1, false, 32, 2);
+            if (bk == 32 && nst == 3) DCASE(64, 64, 1, 1, false, 32, 3);
+            if (bk == 16 && nst == 2) DCASE(64, 64, 1, 1, false, 16, 2);
+            if (bk == 16 && nst == 3) DCASE(64, 64, 1, 1, false, 16, 3);
+        } else if (tk == 128064) {
+            if (bk == 32 && nst == 2) DCASE(128, 64, 1, 1, false, 32, 2);
+            if (bk == 32 && nst == 3) DCASE(128, 64, 1, 1, false, 32, 3);
+            if (bk == 16 && nst == 2) DCASE(128, 64, 1, 1, false, 16, 2);
+            if (bk == 16 && nst == 3) DCASE(128, 64, 1, 1, false, 16, 3);
+        } else if (tk == 128128) {
+            if (bk == 32 && nst == 2) DCASE(128, 128, 1, 1, false, 32, 2);
+            if (bk == 32 && nst == 3) DCASE(128, 128, 1, 1, false, 32, 3);
+            if (bk == 16 && nst == 2) DCASE(128, 128, 1, 1, false, 16, 2);
+            if (bk == 16 && nst == 3) DCASE(128, 128, 1, 1, false, 16, 3);
+        }
+    } else if (key == 310) {
+        if (tk == 64064) {
+            if (bk == 32 && nst == 2) DCASE(64, 64, 3, 1, false, 32, 2);
+            if (bk == 32 && nst == 3) DCASE(64, 64, 3, 1, false, 32, 3);
+            if (bk == 16 && nst == 2) DCASE(64, 64, 3, 1, false, 16, 2);
+            if (bk == 16 && nst == 3) DCASE(64, 64, 3, 1, false, 16, 3);
+        } else if (tk == 128064) {
+            if (bk == 16 && nst == 2) DCASE(128, 64, 3, 1, false, 16, 2);
+            if (bk == 16 && nst == 3) DCASE(128, 64, 3, 1, false, 16, 3);
+        } else if (tk == 128128) {
+            if (bk == 16 && nst == 2) DCASE(128, 128, 3, 1, false, 16, 2);
+            if (bk == 16 && nst == 3) DCASE(128, 128, 3, 1, false, 16, 3);
+        }
+    } else if (key == 320 && tk == 64064) {
+        if (bk == 32 && nst == 2) DCASE(64, 64, 3, 2, false, 32, 2);
+        if (bk >= 16 && nst == 3) DCASE(64, 64, 3, 2, false, 16, 3);
+        if (bk == 16 && nst == 2) DCASE(64, 64, 3, 2, false, 16, 2);
+    } else if (key == 311 && tk == 64064) {
+        if (bk == 32 && nst == 2) DCASE(64, 64, 3, 1, true, 32, 2);
+        if (bk >= 16 && nst == 3) DCASE(64, 64, 3, 1, true, 16, 3);
+        if (bk == 16 && nst == 2) DCASE(64, 64, 3, 1, true, 16, 2);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lds

@@ -1,0 +1,21 @@
+// K4P: the k-interleaved, padded activation layout used between the UNet's kernels.
+//
+//   tensor [B][C][T] (C % 8 == 0)  ->  [B][C/8][2][T+2][4]
+//   channel c = 8q + 2j + h, frame t  ->  ((((b*(C/8) + q)*2 + h)*(T+2) + (t+1))*4 + j
+//
+// * v_mfma_f32_32x32x2_f32 wants, per lane, ONE scalar of A/B whose k index is 2*kp + (lane>>5).  With this
+//   layout the 4 floats at one (row, frame) are the operands of four consecutive MFMAs for lane half h, so an
+//   LDS copy of a row segment serves ds_read_b128 operand loads with no transpose and no VALU.
+// * frames -1 and T of every row are zero: they are the k3 convolutions' padding, so activation tiles are pure
+//   linear copies (LDS-DMA).  Every kernel that writes a K4P tensor also writes its two pad frames.
+// * channel concatenation = concatenation of 8-channel blocks, so the UNet's skip-concat is a second base pointer.
+#pragma once
+
+namespace lds {
+
+__host__ __device__ inline long long k4p_index(int C, int T, int b, int c, int t) {
+    return ((((long long)b * (C >> 3) + (c >> 3)) * 2 + (c & 1)) * (T + 2) + (t + 1)) * 4 + ((c & 7) >> 1);
+}
+__host__ __device__ inline long long k4p_floats(int B, int C, int T) { return (long long)B * C * (T + 2); }
+
+}  // namespace lds

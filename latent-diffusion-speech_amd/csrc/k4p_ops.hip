@@ -1,0 +1,238 @@
+// Memory-bound companions of conv_dma over K4P activations (k4p.h): layout conversion at the UNet boundary,
+// GroupNorm(+scale/shift)(+SiLU) and LayerNorm materialised ONCE per tensor (reference nn.GroupNorm / SiLU in
+// resnet.py:591-641, transformer_1d.py:134,262; nn.LayerNorm in attention.py:83,102,118), nearest resampling.
+// An 8-channel block of a K4P tensor is one contiguous run of 2*(T+2)*4 floats, so all of these stream 16-byte
+// entries with unit stride; the GroupNorm statistics are per-block partials (one workgroup per block) combined
+// with Chan's formula, never atomics, so results do not depend on scheduling.
+#include "k4p.h"
+#include "kernels.h"
+
+#include <math.h>
+
+namespace lds {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int NT>
+static __device__ __forceinline__ float bsum(float v, float* red) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// one workgroup per (b, 8-channel block)
+__global__ void __launch_bounds__(256) to_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int Ctot, int c_off) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int Tp = T + 2;
+    float* ob = out + (((long long)b * (Ctot >> 3) + (c_off >> 3) + q) * 2) * Tp * 4;
+    const float* ib = in + ((long long)b * C + q * 8) * T;
+    for (int idx = threadIdx.x; idx < 2 * Tp; idx += 256) {
+        const int hh = idx / Tp, e = idx - hh * Tp, t = e - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ib[(long long)(2 * j + hh) * T + t];
+        }
+        *reinterpret_cast<f32x4*>(ob + (long long)idx * 4) = v;
+    }
+}
+hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
+    if ((C & 7) || (Ctot & 7) || (c_off & 7)) return hipErrorInvalidValue;
+    ProfScope ps(s, "to_k4p", 0.0, 8.0 * B * (double)C * T);
+    hipLaunchKernelGGL(to_k4p_kernel, dim3(C / 8, B), dim3(256), 0, s, in, out, C, T, Ctot, c_off);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) from_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int Tp = T + 2;
+    const float* ib = in + (((long long)b * (C >> 3) + q) * 2) * Tp * 4;
+    float* ob = out + ((long long)b * C + q * 8) * T;
+    for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
+        const int hh = idx / T, t = idx - hh * T;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ib + ((long long)hh * Tp + t + 1) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[(long long)(2 * j + hh) * T + t] = v[j];
+    }
+}
+hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hipStream_t s) {
+    if (C & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(from_k4p_kernel, dim3(C / 8, B), dim3(256), 0, s, in, out, C, T);
+    return hipGetLastError();
+}
+
+// ---- GroupNorm: pass 1, per 8-channel block (mean, M2) over its 8*T real elements ----
+__global__ void __launch_bounds__(256) gn_part_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
+                                                      float4* __restrict__ part) {
+    __shared__ float red[4];
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int Tp = T + 2, nq1 = C1 >> 3;
+    const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
+        const int hh = idx / T, t = idx - hh * T;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float n = 8.0f * (float)T;
+    const float mean = bsum<256>(s, red) / n;
+    float m2 = 0.f;
+    for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
+        const int hh = idx / T, t = idx - hh * T;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; m2 += d * d; }
+    }
+    m2 = bsum<256>(m2, red);
+    if (threadIdx.x == 0) part[(long long)b * ((C1 + C2) >> 3) + q] = make_float4(mean, m2, n, 0.f);
+}
+
+// ---- GroupNorm: pass 2, combine the group's block partials, normalise + affine (+scale/shift) (+SiLU), write K4P ----
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
+                                                       int groups, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ss, int ss_stride, int ss_off, int silu,
+                                                       const float4* __restrict__ part, float* __restrict__ y) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
+    const int bpg = nq / groups;                     // 8-channel blocks per group
+    const int g0 = (q / bpg) * bpg;
+    float mean = 0.f, m2 = 0.f, n = 0.f;
+    for (int i = 0; i < bpg; ++i) {                  // Chan's parallel combination, fixed order
+        const float4 pp = part[(long long)b * nq + g0 + i];
+        const float d = pp.x - mean, nn = n + pp.z;
+        mean += d * (pp.z / nn);
+        m2 += pp.y + d * d * (n * pp.z / nn);
+        n = nn;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / n + eps);
+    // per-channel coefficients of this block: v = (x - mean) * a + bb
+    float a[2][4], bb[2][4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = q * 8 + 2 * j + hh;
+            float aa = rstd * gamma[ci], be = beta[ci];
+            if (ss) {
+                const float sc = 1.0f + ss[(long long)b * ss_stride + ss_off + ci];
+                const float sh = ss[(long long)b * ss_stride + ss_off + C + ci];
+                aa *= sc;
+                be = be * sc + sh;
+            }
+            a[hh][j] = aa; bb[hh][j] = be;
+        }
+    const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
+    float* yb = y + (((long long)b * nq + q) * 2) * Tp * 4;
+    for (int idx = threadIdx.x; idx < 2 * Tp; idx += 256) {
+        const int hh = idx / Tp, e = idx - hh * Tp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e >= 1 && e <= T) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long long)idx * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float r = (xv[j] - mean) * a[hh][j] + bb[hh][j];
+                if (silu) r = r / (1.0f + expf(-r));
+                v[j] = r;
+            }
+        }
+        *reinterpret_cast<f32x4*>(yb + (long long)idx * 4) = v;      // pad frames written as zeros
+    }
+}
+
+hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                           const float* beta, const float* ss, int ss_stride, int ss_off, int silu, float4* part, float* y, int B,
+                           hipStream_t s) {
+    const int C = C1 + C2;
+    if ((C1 & 7) || (C2 & 7) || (C / 8) % groups) return hipErrorInvalidValue;
+    {
+        ProfScope ps(s, "gn_part", 0.0, 4.0 * 2.0 * B * (double)C * T);
+        hipLaunchKernelGGL(gn_part_kernel, dim3(C / 8, B), dim3(256), 0, s, x1, x2 ? x2 : x1, C1, C2, T, part);
+    }
+    ProfScope ps(s, "gn_apply", 0.0, 4.0 * 2.0 * B * (double)C * T);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(C / 8, B), dim3(256), 0, s, x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride,
+                       ss_off, silu, part, y);
+    return hipGetLastError();
+}
+
+// ---- LayerNorm over channels: block = 64 frames of one batch element; stats from the producer's partials ----
+__global__ void __launch_bounds__(256) ln_apply_kernel(const float* __restrict__ x, const float2* __restrict__ part, int C, int T, float eps,
+                                                       const float4* __restrict__ gb, float* __restrict__ y) {
+    __shared__ float smean[64], srstd[64];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int Tp = T + 2, np = C >> 5, nq = C >> 3;
+    if (threadIdx.x < 64) {
+        const int t = t0 + threadIdx.x;
+        float mean = 0.f, m2 = 0.f, n = 0.f;
+        if (t < T) {
+            for (int i = 0; i < np; ++i) {
+                const float2 pr = part[((long long)b * np + i) * T + t];
+                const float d = pr.x - mean, nn = n + 32.f;
+                mean += d * (32.f / nn);
+                m2 += pr.y + d * d * (n * 32.f / nn);
+                n = nn;
+            }
+        }
+        smean[threadIdx.x] = mean;
+        srstd[threadIdx.x] = (t < T) ? 1.0f / sqrtf(m2 / n + eps) : 0.f;
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 63, rsel = threadIdx.x >> 6;      // 4 row slots x 64 frames
+    const int t = t0 + tl;
+    const float mu = smean[tl], rs = srstd[tl];
+    const float* xb = x + (long long)b * C * Tp;
+    float* yb = y + (long long)b * C * Tp;
+    for (int row = rsel; row < 2 * nq; row += 4) {              // row = q*2 + hh
+        const int q = row >> 1, hh = row & 1;
+        if (t < T) {
+            const long long off = ((long long)row * Tp + t + 1) * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + off);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 g = gb[q * 8 + 2 * j + hh];
+                v[j] = (xv[j] - mu) * (rs * g.x) + g.y;
+            }
+            *reinterpret_cast<f32x4*>(yb + off) = v;
+        }
+        if (t == 0) *reinterpret_cast<f32x4*>(yb + ((long long)row * Tp) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t == T - 1) *reinterpret_cast<f32x4*>(yb + ((long long)row * Tp + T + 1) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+hipError_t launch_ln_apply(const float* x, const float2* part, int C, int T, float eps, const float4* gb, float* y, int B, hipStream_t s) {
+    if (C & 31) return hipErrorInvalidValue;
+    ProfScope ps(s, "ln_apply", 0.0, 4.0 * 2.0 * B * (double)C * T);
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, part, C, T, eps, gb, y);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) resample_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int Tin, int Tout) {
+    const long long row = blockIdx.x;                // (b, q, hh) flattened
+    const float sc = (float)Tin / (float)Tout;
+    const float* ib = in + row * (Tin + 2) * 4;
+    float* ob = out + row * (Tout + 2) * 4;
+    for (int e = threadIdx.x; e < Tout + 2; e += 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e >= 1 && e <= Tout) {
+            int src = (int)floorf((float)(e - 1) * sc);
+            if (src > Tin - 1) src = Tin - 1;
+            v = *reinterpret_cast<const f32x4*>(ib + (long long)(src + 1) * 4);
+        }
+        *reinterpret_cast<f32x4*>(ob + (long long)e * 4) = v;
+    }
+}
+hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s) {
+    hipLaunchKernelGGL(resample_k4p_kernel, dim3((unsigned)((long long)B * C / 4)), dim3(256), 0, s, in, out, Tin, Tout);
+    return hipGetLastError();
+}
+
+}  // namespace lds

@@ -59,6 +59,47 @@ const char* conv_gemm_last_config();
 size_t packed_conv_elems(int Co, int Ci, int K, int* Mp_out);
 
 // ---------------------------------------------------------------------------------------------
+// conv_dma: the UNet's VALU-free GEMM over K4P activations (k4p.h, conv_dma.hip)
+// ---------------------------------------------------------------------------------------------
+struct DmaConvArgs {
+    const float* x1; const float* x2;   // K4P sources [B][C1][Tsrc], [B][C2][Tsrc] (virtual channel concat)
+    int C1, C2, Tsrc;
+    const float* w;                     // packed weights [KT][Ci/8][2][Mp][4]
+    const float* bias;                  // packed-row bias [Mp] or null
+    int Mp, Co, Ci, KT, stride, pad, ups;
+    const float* res;                   // K4P residual [B][Cout(K4P part)][To] or null
+    int epi;                            // EPI_NONE | EPI_GEGLU
+    float* out;                         // K4P [B][min(Cout, plain_from)][To], or plain [B][Cout][To] when out_plain
+    int out_plain;
+    int plain_from; float* out2;        // output channels >= plain_from go frame-major to out2 [B][Cout-plain_from][To]
+    float2* lnpart_out;                 // optional [B][C/32][To] per-frame (mean, M2) partials over 32-channel tiles
+    int Cout, To, B;
+};
+// cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
+hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
+const char* conv_dma_last_config();
+
+// ---------------------------------------------------------------------------------------------
+// K4P helpers (k4p_ops.hip)
+// ---------------------------------------------------------------------------------------------
+// plain [B][C][T] -> channels [c_off, c_off+C) of a K4P tensor with Ctot channels (pads of those rows zeroed)
+hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s);
+hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hipStream_t s);
+// GroupNorm of the virtual concat [x1;x2] (K4P) -> y (K4P, C1+C2 channels):
+//   y = act(((x - mean_g) * rstd_g * gamma + beta) * (1 + scale) + shift), act = SiLU if silu
+// `part` is scratch for [B][(C1+C2)/8] float4 partial statistics.
+hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps,
+                           const float* gamma, const float* beta, const float* scale_shift, int ss_stride, int ss_off,
+                           int silu, float4* part, float* y, int B, hipStream_t s);
+// LayerNorm over channels from the producer's 32-channel partials: y = (x - mean_t) * rstd_t * gamma + beta (K4P -> K4P)
+hipError_t launch_ln_apply(const float* x, const float2* part, int C, int T, float eps, const float4* gamma_beta, float* y, int B,
+                           hipStream_t s);
+// nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
+hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
+// self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v frame-major [B][C][T]; out K4P [B][C][T]
+hipError_t launch_attention_k4p(const float* qk, const float* v, float* out, int B, int C, int T, int heads, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
 // Normalisation statistics
 // ---------------------------------------------------------------------------------------------
 // GroupNorm over the virtual concat [x1;x2] -> coef[b][ci] = {mean_g, rstd_g*gamma*(1+scale), beta*(1+scale)+shift, 0}

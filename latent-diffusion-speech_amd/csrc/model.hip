@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -265,6 +266,47 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     return LDS_OK;
 }
 
+// DMA-fed K4P convolution (conv_dma.hip)
+struct DOpt {
+    int stride = 1, pad = 0, ups = 0;
+    const float* res = nullptr;
+    int epi = EPI_NONE, out_plain = 0, plain_from = -1;
+    float* out2 = nullptr;
+    float2* lnpart_out = nullptr;
+    int cfg = 0;
+};
+static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B,
+                     hipStream_t st) {
+    DmaConvArgs a;
+    memset(&a, 0, sizeof(a));
+    if (C1 + C2 != W.Ci) return fail(LDS_EINVAL, "dconv: input channels %d+%d != %d", C1, C2, W.Ci);
+    a.x1 = x1; a.x2 = x2 ? x2 : x1; a.C1 = C1; a.C2 = C2; a.Tsrc = Tsrc;
+    a.w = W.w; a.bias = W.bias; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
+    a.stride = o.stride; a.pad = o.pad; a.ups = o.ups;
+    a.res = o.res; a.epi = o.epi; a.out = out; a.out_plain = o.out_plain;
+    a.Cout = (o.epi == EPI_GEGLU) ? W.Co / 2 : W.Co;
+    a.plain_from = (o.plain_from >= 0) ? o.plain_from : a.Cout;
+    a.out2 = o.out2; a.lnpart_out = o.lnpart_out;
+    const int Tin = o.ups ? 2 * Tsrc : Tsrc;
+    a.To = (Tin + 2 * o.pad - (W.K - 1) - 1) / o.stride + 1;
+    a.B = B;
+    const double flops = 2.0 * B * (double)a.To * (double)W.Co * (double)W.Ci * (double)W.K;
+    const double bytes = 4.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
+    hipError_t e;
+    {
+        ProfScope ps(st, "conv_dma", flops, bytes);
+        e = launch_conv_dma(a, o.cfg, st);
+    }
+    if (g_prof_on && !g_prof.empty() && g_prof.back().name == "conv_dma") {
+        std::string cfgs(conv_dma_last_config());
+        g_prof.back().name = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+    }
+    if (e != hipSuccess)
+        return fail(LDS_EHIP, "conv_dma launch failed (%s): Co %d Ci %d K %d stride %d ups %d To %d", hipGetErrorString(e), W.Co, W.Ci, W.K,
+                    o.stride, o.ups, a.To);
+    return LDS_OK;
+}
+
 // ================================================================================================
 // UNet
 // ================================================================================================
@@ -517,13 +559,17 @@ extern "C" void lds_unet_destroy(lds_unet* u) { delete u; }
 
 static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
 
+// All UNet activations between kernels are K4P tensors (k4p.h): floats(C, T) = C * (T + 2) per batch element.
 struct UnetWs {
     float *e1, *emb, *tproj;
-    float4* coef;
+    float4* part;
     float2* lnp;
+    float* xin;
     std::vector<float*> skips;
-    float *cur[2], *r, *h1, *sc, *ta, *tb, *qkv, *att, *ff, *upt;
+    float *cur[2], *r, *h1, *sc, *ta, *tb, *upt, *gno, *lnb, *qk, *v, *att, *ff;
 };
+
+static size_t k4(int C, int T) { return (size_t)C * (T + 2); }
 
 static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     const int nb = u->cfg.n_blocks, L = u->cfg.n_layers;
@@ -531,41 +577,43 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.e1 = A.f((size_t)B * u->temb);
     w.emb = A.f((size_t)B * u->temb);
     w.tproj = A.f((size_t)B * u->tp_M);
-    w.coef = (float4*)A.f((size_t)B * u->max_ci * 4);
-    size_t maxct = 0, maxqkv = 0;
-    int Tl = T;
+    w.part = (float4*)A.f((size_t)B * (u->max_ci / 8) * 4);
+    w.xin = A.f(B * k4(u->M + u->H, T));
+    std::vector<int> Ts{T};
+    for (int i = 0; i < nb - 1; ++i) Ts.push_back(down_len(Ts.back()));
+    size_t maxct = 0, maxgn = k4(boc[0], T), maxatt = 0;
     w.skips.clear();
-    w.skips.push_back(A.f((size_t)B * boc[0] * Tl));
+    w.skips.push_back(A.f(B * k4(boc[0], T)));
     for (int i = 0; i < nb; ++i) {
-        const size_t ct = (size_t)boc[i] * Tl;
-        if (ct > maxct) maxct = ct;
-        if (i > 0 && (size_t)boc[i - 1] * Tl > maxct) maxct = (size_t)boc[i - 1] * Tl;
-        if (i != nb - 1 && ct > maxqkv) maxqkv = ct;
-        for (int j = 0; j < L; ++j) w.skips.push_back(A.f((size_t)B * ct));
-        if (i != nb - 1) {
-            Tl = down_len(Tl);
-            w.skips.push_back(A.f((size_t)B * boc[i] * Tl));
-        }
+        const int Tl = Ts[i];
+        maxct = std::max(maxct, k4(boc[i], Tl));
+        maxgn = std::max(maxgn, k4(boc[i], Tl));
+        if (i > 0) maxgn = std::max(maxgn, k4(boc[i - 1], Tl));
+        if (i != nb - 1) maxatt = std::max(maxatt, k4(boc[i], Tl));
+        for (int j = 0; j < L; ++j) w.skips.push_back(A.f(B * k4(boc[i], Tl)));
+        if (i != nb - 1) w.skips.push_back(A.f(B * k4(boc[i], Ts[i + 1])));
     }
-    // the up path revisits the same resolutions with channel counts <= max(boc) at each level
+    maxatt = std::max(maxatt, k4(boc[nb - 1], Ts[nb - 1]));
+    // up path: block i works at resolution nb-1-i with out channels boc[nb-1-i]; resnet inputs are (hidden + skip) channels
     {
-        int Tu = T;
-        std::vector<int> Ts{T};
-        for (int i = 0; i < nb - 1; ++i) { Tu = down_len(Tu); Ts.push_back(Tu); }
+        int prev = boc[nb - 1];
         for (int i = 0; i < nb; ++i) {
-            const int lvl = nb - 1 - i;              // resolution index of up block i
-            const size_t ct = (size_t)boc[nb - 1 - i] * Ts[lvl];
-            if (ct > maxct) maxct = ct;
-            if (i != 0 && ct > maxqkv) maxqkv = ct;
-            if (lvl > 0) { const size_t c2 = (size_t)boc[nb - 1 - i] * Ts[lvl - 1]; if (c2 > maxct) maxct = c2; }
+            const int lvl = nb - 1 - i, co = boc[lvl], Tl = Ts[lvl];
+            maxct = std::max(maxct, k4(co, Tl));
+            if (lvl > 0) maxct = std::max(maxct, k4(co, Ts[lvl - 1]));
+            if (i != 0) maxatt = std::max(maxatt, k4(co, Tl));
+            maxgn = std::max(maxgn, k4(prev + boc[nb - 1], Tl));   // upper bound: hidden + widest skip
+            maxgn = std::max(maxgn, k4(2 * std::max(prev, co), Tl));
+            prev = co;
         }
-        if ((size_t)boc[nb - 1] * Ts[nb - 1] > maxqkv) maxqkv = (size_t)boc[nb - 1] * Ts[nb - 1];
     }
     w.cur[0] = A.f(B * maxct); w.cur[1] = A.f(B * maxct);
     w.r = A.f(B * maxct); w.h1 = A.f(B * maxct); w.sc = A.f(B * maxct);
     w.ta = A.f(B * maxct); w.tb = A.f(B * maxct); w.upt = A.f(B * maxct);
-    w.qkv = A.f(B * maxqkv * 3); w.att = A.f(B * maxqkv); w.ff = A.f(B * maxqkv * 4);
-    w.lnp = (float2*)A.f(B * (maxqkv / 32) * 2);
+    w.gno = A.f(B * maxgn);
+    w.lnb = A.f(B * maxatt); w.qk = A.f(B * maxatt * 2); w.v = A.f(B * maxatt); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
+    w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2);
+    A.f(16384);   // tail slack: ragged last tiles read (masked) entries past a tensor's end
 }
 
 extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t* out) {
@@ -579,63 +627,55 @@ extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t*
 
 static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, const float* x1, int C1, const float* x2, int C2, int T,
                       float* out, int B, hipStream_t st) {
-    // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut
-    HIP_TRY(launch_gn_coef(x1, x2 ? x2 : x1, C1, C2, T, (long long)C1 * T, (long long)C2 * T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0,
-                           w.coef, B, st));
-    Src s{x1, C1, x2, C2, T};
-    ConvOpt o1;
-    o1.pad = 1; o1.norm_mode = NORM_ROWCOEF; o1.coef = w.coef; o1.act_in = ACT_SILU;
-    LDS_TRY(run_conv(r.conv1, s, o1, w.h1, B, st));
+    // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut.
+    // GroupNorm(+scale/shift)+SiLU is materialised once (gn_apply) so the convolutions stay VALU-free.
+    HIP_TRY(launch_gn_apply(x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.part, w.gno, B, st));
+    DOpt o1;
+    o1.pad = 1;
+    LDS_TRY(run_dconv(r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
     const float* res = x1;
     if (r.has_sc) {
-        ConvOpt os;
-        LDS_TRY(run_conv(r.sc, s, os, w.sc, B, st));
+        DOpt os;
+        LDS_TRY(run_dconv(r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));   // skip-concat on read: second source pointer
         res = w.sc;
     }
-    HIP_TRY(launch_gn_coef(w.h1, w.h1, r.cout, 0, T, (long long)r.cout * T, 0, u->G, 1e-5f, r.g2, r.b2, w.tproj, u->tp_M, r.temb_off,
-                           w.coef, B, st));
-    Src s2{w.h1, r.cout, nullptr, 0, T};
-    ConvOpt o2;
-    o2.pad = 1; o2.norm_mode = NORM_ROWCOEF; o2.coef = w.coef; o2.act_in = ACT_SILU; o2.res = res;
-    return run_conv(r.conv2, s2, o2, out, B, st);
+    HIP_TRY(launch_gn_apply(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, u->tp_M, r.temb_off, 1, w.part, w.gno, B, st));
+    DOpt o2;
+    o2.pad = 1; o2.res = res;
+    return run_dconv(r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
 }
 
 static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st) {
-    // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major.  Every conv that feeds a
-    // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer combines them on load.
+    // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major (K4P).  Every conv that feeds a
+    // LayerNorm also emits per-32-channel (mean, M2) partials per frame; ln_apply combines them.
     const int C = t.C;
-    HIP_TRY(launch_gn_coef(x, x, C, 0, T, (long long)C * T, 0, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, w.coef, B, st));
-    Src sx{x, C, nullptr, 0, T};
-    ConvOpt op;
-    op.norm_mode = NORM_ROWCOEF; op.coef = w.coef; op.lnpart_out = w.lnp;
-    LDS_TRY(run_conv(t.proj_in, sx, op, w.ta, B, st));
+    HIP_TRY(launch_gn_apply(x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.part, w.gno, B, st));
+    DOpt op;
+    op.lnpart_out = w.lnp;
+    LDS_TRY(run_dconv(t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
-        Src sh{h, C, nullptr, 0, T};
-        ConvOpt oq;
-        oq.norm_mode = NORM_COLSTAT; oq.lnpart = w.lnp; oq.ln_np = C / 32; oq.ln_eps = 1e-5f; oq.coef = t.ln_gb[a];
-        LDS_TRY(run_conv(t.qkv[a], sh, oq, w.qkv, B, st));
-        { ProfScope ps(st, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T); HIP_TRY(launch_attention(w.qkv, w.att, B, C, T, u->heads, st)); }
-        Src sa{w.att, C, nullptr, 0, T};
-        ConvOpt oo;
+        HIP_TRY(launch_ln_apply(h, w.lnp, C, T, 1e-5f, t.ln_gb[a], w.lnb, B, st));
+        DOpt oq;
+        oq.plain_from = 2 * C; oq.out2 = w.v;                      // q, k in K4P; v frame-major for the P.V operand reads
+        LDS_TRY(run_dconv(t.qkv[a], w.lnb, C, nullptr, 0, T, oq, w.qk, B, st));
+        HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
+        DOpt oo;
         oo.res = h; oo.lnpart_out = w.lnp;
-        LDS_TRY(run_conv(t.o[a], sa, oo, hn, B, st));
+        LDS_TRY(run_dconv(t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
         float* tmp = h; h = hn; hn = tmp;
     }
-    Src sh{h, C, nullptr, 0, T};
-    ConvOpt of;
-    of.norm_mode = NORM_COLSTAT; of.lnpart = w.lnp; of.ln_np = C / 32; of.ln_eps = 1e-5f; of.coef = t.ln_gb[2];
+    HIP_TRY(launch_ln_apply(h, w.lnp, C, T, 1e-5f, t.ln_gb[2], w.lnb, B, st));
+    DOpt of;
     of.epi = EPI_GEGLU;
-    LDS_TRY(run_conv(t.ff1, sh, of, w.ff, B, st));
-    Src sf{w.ff, 4 * C, nullptr, 0, T};
-    ConvOpt o2;
+    LDS_TRY(run_dconv(t.ff1, w.lnb, C, nullptr, 0, T, of, w.ff, B, st));
+    DOpt o2;
     o2.res = h;
-    LDS_TRY(run_conv(t.ff2, sf, o2, hn, B, st));
-    Src so{hn, C, nullptr, 0, T};
-    ConvOpt o3;
+    LDS_TRY(run_dconv(t.ff2, w.ff, 4 * C, nullptr, 0, T, o2, hn, B, st));
+    DOpt o3;
     o3.res = x;
-    return run_conv(t.proj_out, so, o3, out, B, st);
+    return run_dconv(t.proj_out, hn, C, nullptr, 0, T, o3, out, B, st);
 }
 
 static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
@@ -645,19 +685,21 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
     const int nb = u->cfg.n_blocks;
-    // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch
+    // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch.
     // e1 = SiLU(linear_1(sinusoid(t))); emb = SiLU(linear_2(e1)) -- every consumer of emb applies SiLU first
     // (resnet.py:610), so only the activated embedding is stored
     HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, 1, u->temb, u->tproj_dim, B, st));
     HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_PLAIN, nullptr, w.emb, u->temb, 1, u->temb, u->temb, B, st));
     HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_PLAIN, nullptr, w.tproj, u->tp_M, 0, u->tp_M, u->temb, B, st));
-    // conv_in over the virtual concat [x ; cond] (reference diffusion.py:105, unet_1d_condition.py:943)
+    // the virtual concat [x ; cond] (reference diffusion.py:105) becomes one K4P tensor
+    const int cin = u->M + u->H;
+    HIP_TRY(launch_to_k4p(x, w.xin, B, u->M, T, cin, 0, st));
+    HIP_TRY(launch_to_k4p(cond, w.xin, B, u->H, T, cin, u->M, st));
     size_t si = 0;
     {
-        Src s{x, u->M, cond, u->H, T};
-        ConvOpt o;
+        DOpt o;
         o.pad = 1;
-        LDS_TRY(run_conv(u->conv_in, s, o, w.skips[si], B, st));
+        LDS_TRY(run_dconv(u->conv_in, w.xin, cin, nullptr, 0, T, o, w.skips[si], B, st));
     }
     const float* cur = w.skips[si++];
     int Tl = T;
@@ -674,16 +716,14 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             skipT.push_back(Tl);
         }
         if (d.has_down) {
-            Src s{cur, d.ch, nullptr, 0, Tl};
-            ConvOpt o;
+            DOpt o;
             o.pad = 1; o.stride = 2;
-            LDS_TRY(run_conv(d.down, s, o, w.skips[si], B, st));
+            LDS_TRY(run_dconv(d.down, cur, d.ch, nullptr, 0, Tl, o, w.skips[si], B, st));
             Tl = down_len(Tl);
             cur = w.skips[si++];
             skipT.push_back(Tl);
         }
     }
-    // mid
     LDS_TRY(run_resnet(u, u->mid_r0, w, cur, u->mid_r0.cin, nullptr, 0, Tl, w.cur[0], B, st));
     LDS_TRY(run_tfm(u, u->mid_t, w, w.cur[0], Tl, w.cur[1], B, st));
     LDS_TRY(run_resnet(u, u->mid_r1, w, w.cur[1], u->mid_r1.cin, nullptr, 0, Tl, w.cur[0], B, st));
@@ -707,29 +747,26 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             // reference resnet.py:137-173: nearest x2 (or size= of the next skip when T % 2^n != 0) then conv k3
             const int Tn = skipT[si - 1];
             float* dst = w.cur[ci ^ 1];
-            ConvOpt o;
+            DOpt o;
             o.pad = 1;
             if (Tn == 2 * Tl) {
                 o.ups = 1;
-                Src s{cur, b.ch, nullptr, 0, Tl};
-                LDS_TRY(run_conv(b.up, s, o, dst, B, st));
+                LDS_TRY(run_dconv(b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
             } else {
-                HIP_TRY(launch_resample_nearest(cur, w.upt, B, b.ch, Tl, Tn, st));
-                Src s{w.upt, b.ch, nullptr, 0, Tn};
-                LDS_TRY(run_conv(b.up, s, o, dst, B, st));
+                HIP_TRY(launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st));
+                LDS_TRY(run_dconv(b.up, w.upt, b.ch, nullptr, 0, Tn, o, dst, B, st));
             }
             Tl = Tn;
             cur = dst;
             ci ^= 1;
         }
     }
-    // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031)
+    // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031); eps leaves in the caller's frame-major layout
     const int c0 = u->cfg.block_out_channels[0];
-    HIP_TRY(launch_gn_coef(cur, cur, c0, 0, Tl, (long long)c0 * Tl, 0, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, w.coef, B, st));
-    Src s{cur, c0, nullptr, 0, Tl};
-    ConvOpt o;
-    o.pad = 1; o.norm_mode = NORM_ROWCOEF; o.coef = w.coef; o.act_in = ACT_SILU;
-    return run_conv(u->conv_out, s, o, eps, B, st);
+    HIP_TRY(launch_gn_apply(cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.part, w.gno, B, st));
+    DOpt o;
+    o.pad = 1; o.out_plain = 1;
+    return run_dconv(u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st);
 }
 
 extern "C" int lds_unet_forward(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
@@ -1175,6 +1212,162 @@ extern "C" int lds_bench_conv(const lds_conv_test* a, float* out, int B, int ite
     return r;
 }
 
+
+// ---- K4P path test entry points: plain tensors in / out, converted on the device ----
+struct TmpDev {
+    std::vector<void*> p;
+    ~TmpDev() { for (void* q : p) (void)hipFree(q); }
+    float* f(size_t n) { void* d = nullptr; if (hipMalloc(&d, n * sizeof(float) + 65536) != hipSuccess) return nullptr; p.push_back(d); return (float*)d; }
+};
+
+static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    TmpDev tmp;
+    ConvW W;
+    const int Ci = a->C1 + a->C2, T = a->T;
+    bool ok = (a->epilogue == EPI_GEGLU) ? pack_geglu(own, a->w, a->bias, a->Co, Ci, W) : pack_conv(own, a->w, a->bias, a->Co, Ci, a->K, W);
+    if (!ok) return fail(LDS_ENOMEM, "test dconv: upload failed");
+    float* k1 = tmp.f((size_t)B * a->C1 * (T + 2));
+    float* k2 = a->C2 ? tmp.f((size_t)B * a->C2 * (T + 2)) : nullptr;
+    if (!k1 || (a->C2 && !k2)) return fail(LDS_ENOMEM, "test dconv: alloc failed");
+    HIP_TRY(launch_to_k4p(a->x1, k1, B, a->C1, T, a->C1, 0, st));
+    if (a->C2) HIP_TRY(launch_to_k4p(a->x2, k2, B, a->C2, T, a->C2, 0, st));
+    const int Cout = (a->epilogue == EPI_GEGLU) ? a->Co / 2 : a->Co;
+    const int Tin = a->ups ? 2 * T : T;
+    const int To = (Tin + 2 * a->pad - (a->K - 1) - 1) / a->stride + 1;
+    const int Ck = a->v_split ? (Cout / 3) * 2 : Cout;
+    DOpt o;
+    o.stride = a->stride; o.pad = a->pad; o.ups = a->ups; o.epi = a->epilogue; o.cfg = a->cfg; o.out_plain = a->plain_out;
+    float* kres = nullptr;
+    if (a->res) {
+        kres = tmp.f((size_t)B * Ck * (To + 2));
+        if (!kres) return fail(LDS_ENOMEM, "alloc");
+        HIP_TRY(launch_to_k4p(a->res, kres, B, Ck, To, Ck, 0, st));
+        o.res = kres;
+    }
+    float* kout = a->plain_out ? out : tmp.f((size_t)B * Ck * (To + 2));
+    float* vout = nullptr;
+    if (!kout) return fail(LDS_ENOMEM, "alloc");
+    if (a->v_split) {
+        vout = tmp.f((size_t)B * (Cout - Ck) * To);
+        if (!vout) return fail(LDS_ENOMEM, "alloc");
+        o.plain_from = Ck; o.out2 = vout;
+    }
+    o.lnpart_out = (float2*)lnpart;
+    int r = run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st);
+    if (r == LDS_OK && iters > 0 && ms_out) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+        for (int i = 0; i < iters && r == LDS_OK; ++i) r = run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st);
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    if (r == LDS_OK && !a->plain_out) {
+        if (a->v_split) {
+            // out = [q;k] back to plain (first 2/3 of the channels) followed by the already-plain v third
+            float* tmpo = tmp.f((size_t)B * Ck * To);
+            if (!tmpo) return fail(LDS_ENOMEM, "alloc");
+            HIP_TRY(launch_from_k4p(kout, tmpo, B, Ck, To, st));
+            for (int b = 0; b < B; ++b) {
+                HIP_TRY(hipMemcpyAsync(out + (size_t)b * Cout * To, tmpo + (size_t)b * Ck * To, sizeof(float) * Ck * To, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(out + (size_t)b * Cout * To + (size_t)Ck * To, vout + (size_t)b * (Cout - Ck) * To,
+                                       sizeof(float) * (Cout - Ck) * To, hipMemcpyDeviceToDevice, st));
+            }
+        } else {
+            HIP_TRY(launch_from_k4p(kout, out, B, Ck, To, st));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return r;
+}
+extern "C" int lds_test_dconv(const lds_dconv_test* a, float* out, float* lnpart, int B, void* stream) {
+    if (!a || !out) return fail(LDS_EINVAL, "bad argument");
+    return dconv_test_impl(a, out, lnpart, B, 0, nullptr, stream);
+}
+extern "C" int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap, void* stream) {
+    if (!a || !out || !ms_out || iters <= 0) return fail(LDS_EINVAL, "bad argument");
+    int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream);
+    if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_dma_last_config());
+    return r;
+}
+
+extern "C" int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                                 const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    TmpDev tmp;
+    const int C = C1 + C2;
+    float* g = up_vec(own, gamma, C);
+    float* be = up_vec(own, beta, C);
+    float* k1 = tmp.f((size_t)B * C1 * (T + 2));
+    float* k2 = C2 ? tmp.f((size_t)B * C2 * (T + 2)) : nullptr;
+    float* ky = tmp.f((size_t)B * C * (T + 2));
+    float* part = tmp.f((size_t)B * (C / 8) * 4);
+    if (!g || !be || !k1 || (C2 && !k2) || !ky || !part) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(launch_to_k4p(x1, k1, B, C1, T, C1, 0, st));
+    if (C2) HIP_TRY(launch_to_k4p(x2, k2, B, C2, T, C2, 0, st));
+    HIP_TRY(launch_gn_apply(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (float4*)part, ky, B, st));
+    HIP_TRY(launch_from_k4p(ky, out, B, C, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
+// mid = w1 * x (1x1, emits LayerNorm partials); out = w2 * LayerNorm_C(mid) with the LayerNorm materialised by ln_apply
+extern "C" int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
+                                     float* mid, float* out, int B, int C, int Co, int T, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    TmpDev tmp;
+    ConvW W1, W2;
+    if (!pack_conv(own, w1, nullptr, C, C, 1, W1) || !pack_conv(own, w2, nullptr, Co, C, 1, W2)) return fail(LDS_ENOMEM, "upload failed");
+    std::vector<float> gbv((size_t)4 * C, 0.f);
+    for (int c = 0; c < C; ++c) { gbv[4 * c] = gamma[c]; gbv[4 * c + 1] = beta[c]; }
+    float4* dgb = (float4*)own.upload(gbv);
+    float* kx = tmp.f((size_t)B * C * (T + 2));
+    float* km = tmp.f((size_t)B * C * (T + 2));
+    float* kn = tmp.f((size_t)B * C * (T + 2));
+    float* ko = tmp.f((size_t)B * Co * (T + 2));
+    float* part = tmp.f((size_t)B * (C / 32) * T * 2);
+    if (!dgb || !kx || !km || !kn || !ko || !part) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(launch_to_k4p(x, kx, B, C, T, C, 0, st));
+    DOpt o1;
+    o1.lnpart_out = (float2*)part;
+    LDS_TRY(run_dconv(W1, kx, C, nullptr, 0, T, o1, km, B, st));
+    HIP_TRY(launch_ln_apply(km, (const float2*)part, C, T, eps, dgb, kn, B, st));
+    DOpt o2;
+    LDS_TRY(run_dconv(W2, kn, C, nullptr, 0, T, o2, ko, B, st));
+    HIP_TRY(launch_from_k4p(km, mid, B, C, T, st));
+    HIP_TRY(launch_from_k4p(ko, out, B, Co, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
+extern "C" int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TmpDev tmp;
+    float* qkp = tmp.f((size_t)B * 2 * C * T);       // plain [B][2C][T]
+    float* vpl = tmp.f((size_t)B * C * T);
+    float* kqk = tmp.f((size_t)B * 2 * C * (T + 2));
+    float* ko = tmp.f((size_t)B * C * (T + 2));
+    if (!qkp || !vpl || !kqk || !ko) return fail(LDS_ENOMEM, "alloc");
+    for (int b = 0; b < B; ++b) {
+        HIP_TRY(hipMemcpyAsync(qkp + (size_t)b * 2 * C * T, qkv + (size_t)b * 3 * C * T, sizeof(float) * 2 * C * T, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(vpl + (size_t)b * C * T, qkv + (size_t)b * 3 * C * T + (size_t)2 * C * T, sizeof(float) * C * T, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(launch_to_k4p(qkp, kqk, B, 2 * C, T, 2 * C, 0, st));
+    HIP_TRY(launch_attention_k4p(kqk, vpl, ko, B, C, T, heads, st));
+    HIP_TRY(launch_from_k4p(ko, out, B, C, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
 
 // conv1 (1x1, emits LayerNorm partials) -> conv2 (1x1, LayerNorm-on-load from those partials)
 extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
