@@ -20,7 +20,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int D, int NW>
 __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vp, float* __restrict__ out,
-                                                                int C, int T, float scale) {
+                                                                int C, int T, float scale2) {
     constexpr int DQ = D / 8;              // 8-channel blocks per head
     constexpr int DT = (D + 31) / 32;
     constexpr int KB = 64, VP = 68;
@@ -84,25 +84,30 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], qv[kq][jj], s, 0, 0, 0);
             }
+            // scores are kept in log2 units (scale2 = log2(e)/sqrt(d)) so every exponential is one v_exp_f32; all of this
+            // VALU work is paid in matrix time on gfx950 (the fp32 MFMA shares the vector ALU), so it is kept minimal
             float mt = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                s[r] = (key < T) ? s[r] * scale : -INFINITY;
+                s[r] = (key < T) ? s[r] * scale2 : -INFINITY;
                 mt = fmaxf(mt, s[r]);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = expf(m_run - m_new);
             float ls = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ls += s[r]; }
-            l_run = l_run * alpha + ls;
-            m_run = m_new;
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
+            if (__any(m_new != m_run)) {             // wave-uniform: rescale only when some query's running maximum moved
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+                for (int i = 0; i < DT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                m_run = m_new;
+            }
+            l_run += ls;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -136,7 +141,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 
 template <int D>
 static hipError_t launch_dk(const float* qk, const float* v, float* out, int B, int C, int T, int heads, hipStream_t s) {
-    const float scale = 1.0f / sqrtf((float)D);
+    const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
     if (T > 64) hipLaunchKernelGGL((attention_k4p_kernel<D, 4>), dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qk, v, out, C, T, scale);
     else hipLaunchKernelGGL((attention_k4p_kernel<D, 2>), dim3((T + 63) / 64, heads, B), dim3(128), 0, s, qk, v, out, C, T, scale);
     return hipGetLastError();

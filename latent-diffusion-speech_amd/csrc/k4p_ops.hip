@@ -71,30 +71,27 @@ hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hip
     return hipGetLastError();
 }
 
-// ---- GroupNorm: pass 1, per 8-channel block (mean, M2) over its 8*T real elements ----
+// ---- GroupNorm: pass 1, per 8-channel block (mean, M2) over its 8*T real elements.  One read: sums of (x - k) and
+//      (x - k)^2 with k = the block's first element (a shift close to the mean removes the cancellation of the naive
+//      sum / sum-of-squares form); blocks are combined in pass 2 with Chan's formula ----
 __global__ void __launch_bounds__(256) gn_part_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
                                                       float4* __restrict__ part) {
     __shared__ float red[4];
     const int q = blockIdx.x, b = blockIdx.y;
     const int Tp = T + 2, nq1 = C1 >> 3;
     const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
-    float s = 0.f;
-    for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
-        const int hh = idx / T, t = idx - hh * T;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float n = 8.0f * (float)T;
-    const float mean = bsum<256>(s, red) / n;
-    float m2 = 0.f;
+    const float k = xb[4];                     // element (h=0, t=0, j=0)
+    float s1 = 0.f, s2 = 0.f;
     for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
         const int hh = idx / T, t = idx - hh * T;
         const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; m2 += d * d; }
+        for (int j = 0; j < 4; ++j) { const float d = v[j] - k; s1 += d; s2 += d * d; }
     }
-    m2 = bsum<256>(m2, red);
-    if (threadIdx.x == 0) part[(long long)b * ((C1 + C2) >> 3) + q] = make_float4(mean, m2, n, 0.f);
+    s1 = bsum<256>(s1, red);
+    s2 = bsum<256>(s2, red);
+    const float n = 8.0f * (float)T;
+    if (threadIdx.x == 0) part[(long long)b * ((C1 + C2) >> 3) + q] = make_float4(k + s1 / n, fmaxf(s2 - s1 * s1 / n, 0.f), n, 0.f);
 }
 
 // ---- GroupNorm: pass 2, combine the group's block partials, normalise + affine (+scale/shift) (+SiLU), write K4P ----
@@ -164,12 +161,13 @@ hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int
     return hipGetLastError();
 }
 
-// ---- LayerNorm over channels: block = 64 frames of one batch element; stats from the producer's partials ----
+// ---- LayerNorm over channels: block = (64 frames) x (32-channel tile) of one batch element; every block combines the
+//      producer's per-32-channel partials of its frames (Chan, fixed order), then streams its 8 K4P rows ----
 __global__ void __launch_bounds__(256) ln_apply_kernel(const float* __restrict__ x, const float2* __restrict__ part, int C, int T, float eps,
                                                        const float4* __restrict__ gb, float* __restrict__ y) {
     __shared__ float smean[64], srstd[64];
-    const int b = blockIdx.y, t0 = blockIdx.x * 64;
-    const int Tp = T + 2, np = C >> 5, nq = C >> 3;
+    const int b = blockIdx.z, ct = blockIdx.y, t0 = blockIdx.x * 64;
+    const int Tp = T + 2, np = C >> 5;
     if (threadIdx.x < 64) {
         const int t = t0 + threadIdx.x;
         float mean = 0.f, m2 = 0.f, n = 0.f;
@@ -185,23 +183,28 @@ __global__ void __launch_bounds__(256) ln_apply_kernel(const float* __restrict__
         smean[threadIdx.x] = mean;
         srstd[threadIdx.x] = (t < T) ? 1.0f / sqrtf(m2 / n + eps) : 0.f;
     }
-    __syncthreads();
-    const int tl = threadIdx.x & 63, rsel = threadIdx.x >> 6;      // 4 row slots x 64 frames
+    const int tl = threadIdx.x & 63, rsel = threadIdx.x >> 6;      // 4 row slots x 64 frames; 8 rows per tile -> 2 rows per thread
     const int t = t0 + tl;
+    float ga[2][4], be[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int row = ct * 8 + rsel + 4 * k, q = row >> 1, hh = row & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 g = gb[q * 8 + 2 * j + hh]; ga[k][j] = g.x; be[k][j] = g.y; }
+    }
+    __syncthreads();
     const float mu = smean[tl], rs = srstd[tl];
     const float* xb = x + (long long)b * C * Tp;
     float* yb = y + (long long)b * C * Tp;
-    for (int row = rsel; row < 2 * nq; row += 4) {              // row = q*2 + hh
-        const int q = row >> 1, hh = row & 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int row = ct * 8 + rsel + 4 * k;                  // row = q*2 + hh
         if (t < T) {
             const long long off = ((long long)row * Tp + t + 1) * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + off);
             f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 g = gb[q * 8 + 2 * j + hh];
-                v[j] = (xv[j] - mu) * (rs * g.x) + g.y;
-            }
+            for (int j = 0; j < 4; ++j) v[j] = (xv[j] - mu) * (rs * ga[k][j]) + be[k][j];
             *reinterpret_cast<f32x4*>(yb + off) = v;
         }
         if (t == 0) *reinterpret_cast<f32x4*>(yb + ((long long)row * Tp) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256) ln_apply_kernel(const float* __restrict__
 hipError_t launch_ln_apply(const float* x, const float2* part, int C, int T, float eps, const float4* gb, float* y, int B, hipStream_t s) {
     if (C & 31) return hipErrorInvalidValue;
     ProfScope ps(s, "ln_apply", 0.0, 4.0 * 2.0 * B * (double)C * T);
-    hipLaunchKernelGGL(ln_apply_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, part, C, T, eps, gb, y);
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((T + 63) / 64, C / 32, B), dim3(256), 0, s, x, part, C, T, eps, gb, y);
     return hipGetLastError();
 }
 

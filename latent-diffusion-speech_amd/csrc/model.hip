@@ -567,6 +567,7 @@ struct UnetWs {
     float* xin;
     std::vector<float*> skips;
     float *cur[2], *r, *h1, *sc, *ta, *tb, *upt, *gno, *lnb, *qk, *v, *att, *ff;
+    int ss_stride = 0;
 };
 
 static size_t k4(int C, int T) { return (size_t)C * (T + 2); }
@@ -639,7 +640,7 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
         LDS_TRY(run_dconv(r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));   // skip-concat on read: second source pointer
         res = w.sc;
     }
-    HIP_TRY(launch_gn_apply(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, u->tp_M, r.temb_off, 1, w.part, w.gno, B, st));
+    HIP_TRY(launch_gn_apply(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.part, w.gno, B, st));
     DOpt o2;
     o2.pad = 1; o2.res = res;
     return run_dconv(r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
@@ -678,8 +679,10 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     return run_dconv(t.proj_out, hn, C, nullptr, 0, T, o3, out, B, st);
 }
 
+// uniform_t: every batch element shares t[0] (the samplers' case) -> the time-embedding path runs for one column and
+// the resnets read it with batch stride 0
 static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
-                             int B, int T, hipStream_t st) {
+                             int B, int T, hipStream_t st, bool uniform_t = false) {
     Arena A(ws, ws_bytes);
     UnetWs w;
     plan_ws(u, A, B, T, w);
@@ -688,9 +691,11 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch.
     // e1 = SiLU(linear_1(sinusoid(t))); emb = SiLU(linear_2(e1)) -- every consumer of emb applies SiLU first
     // (resnet.py:610), so only the activated embedding is stored
-    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, 1, u->temb, u->tproj_dim, B, st));
-    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_PLAIN, nullptr, w.emb, u->temb, 1, u->temb, u->temb, B, st));
-    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_PLAIN, nullptr, w.tproj, u->tp_M, 0, u->tp_M, u->temb, B, st));
+    const int Bt = uniform_t ? 1 : B;
+    w.ss_stride = uniform_t ? 0 : u->tp_M;
+    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, 1, u->temb, u->tproj_dim, Bt, st));
+    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_PLAIN, nullptr, w.emb, u->temb, 1, u->temb, u->temb, Bt, st));
+    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_PLAIN, nullptr, w.tproj, u->tp_M, 0, u->tp_M, u->temb, Bt, st));
     // the virtual concat [x ; cond] (reference diffusion.py:105) becomes one K4P tensor
     const int cin = u->M + u->H;
     HIP_TRY(launch_to_k4p(x, w.xin, B, u->M, T, cin, 0, st));
@@ -812,7 +817,7 @@ extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float*
     const int S = LDS_TABLE_STRIDE;
     auto model = [&](const float* xin, float t_in) -> int {
         HIP_TRY(launch_fill(s.tvec, t_in, B, st));
-        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st);
+        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st, true);
     };
     float *m0 = s.m0, *m1 = s.m1, *m2 = s.m2;
     if (method == LDS_METHOD_DPM_SOLVER_PP) {
