@@ -318,11 +318,42 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
     } else {
-        if (a.epi == EPI_GEGLU || (a.stride == 1 && !a.ups && blocks(128, 128) >= 512)) { bm = 128; bn = 128; }
-        else { bm = 64; bn = 64; }
-        if (a.epi == EPI_GEGLU && blocks(128, 128) < 384) bn = 64;
-        bk = (a.KT == 1) ? (bm == 128 ? 32 : 64) : (bm == 128 ? 16 : 32);
-        nst = 2;
+        // Pick the tile by a small occupancy model fitted to tools/bench_dconv.py sweeps: a CU runs its n workgroups r at a
+        // time (r = LDS residency, <= 4); r >= 3 co-resident workgroups keep the matrix pipe full, 2 reach ~0.9, a lone one
+        // ~0.62 (nothing hides its barriers / LDS latency).  Short reductions (Ci <= 512) prefer many small stages (BK 16, 3-deep
+        // ring), long ones few big stages (BK 64, 2-deep).
+        struct Cand { int bm, bn, bk, nst; double eff; };
+        Cand cands[3];
+        int nc = 0;
+        if (a.stride == 2 || a.ups) {
+            cands[nc++] = {64, 64, 32, 2, 0.93};
+        } else if (a.KT == 3) {
+            cands[nc++] = {64, 64, 32, 2, 0.93};
+            if (a.Mp % 128 == 0) cands[nc++] = {128, 128, 16, 2, 1.0};
+        } else if (a.epi == EPI_GEGLU) {
+            cands[nc++] = {128, 128, 32, 2, 1.0};
+            cands[nc++] = {128, 64, 32, 3, 0.97};
+        } else {
+            if (a.Ci <= 512) cands[nc++] = {64, 64, 16, 3, 0.93};
+            else cands[nc++] = {64, 64, 64, 2, 0.93};
+            if (a.Mp % 128 == 0) cands[nc++] = {128, 64, 32, 2, 0.97};
+        }
+        double best = 1e300;
+        bm = cands[0].bm; bn = cands[0].bn; bk = cands[0].bk; nst = cands[0].nst;
+        for (int i = 0; i < nc; ++i) {
+            const Cand& c = cands[i];
+            const long long nblk = blocks(c.bm, c.bn);
+            if (nblk < 0) continue;
+            const int xw = a.ups ? c.bn / 2 + 2 : (c.bn - 1) * a.stride + a.KT;
+            const double lds = 4.0 * c.nst * (a.KT * c.bk * c.bm + (c.bk / 4) * xw * 4);
+            int r = (int)(160.0 * 1024 / lds);
+            r = r < 1 ? 1 : (r > 4 ? 4 : r);
+            if (c.bm * c.bn >= 128 * 128 && r > 2) r = 2;
+            const long long n = (nblk + 255) / 256;
+            static const double e[5] = {1.0, 0.62, 0.9, 1.0, 1.0};
+            const double cost = ((double)(n / r) * r / e[r] + (double)(n % r) / e[n % r]) * c.bm * c.bn / c.eff;
+            if (cost < best) { best = cost; bm = c.bm; bn = c.bn; bk = c.bk; nst = c.nst; }
+        }
     }
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     if (a.Mp % bm) return hipErrorInvalidValue;

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float r = (xv[j] - mean) * a[hh][j] + bb[hh][j];
-                if (silu) r = r / (1.0f + expf(-r));
+                if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
                 v[j] = r;
             }
         }
