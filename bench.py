@@ -154,7 +154,7 @@ def main():
         tot_ms = sum(r["ms"] for r in prof)
         dom = prof[0]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        conv = [r for r in prof if r["name"].startswith("conv_gemm")]
+        conv = [r for r in prof if r["name"].startswith("conv_")]
         conv_tf = sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12
         res["roofline"] = {
             "bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

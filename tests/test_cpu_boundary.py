@@ -1,0 +1,195 @@
+"""CPU-side checks (no GPU): the C-ABI library builds, loads and exports every symbol include/lds.h declares; the
+module shells keep the reference's API; the host-side solver tables reproduce the reference samplers; the product
+path fails loudly (no CPU fallback); the seeded initialiser is platform independent."""
+import inspect
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from lds import native
+    if not os.path.exists(native.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j", "8"], check=True, capture_output=True)
+    return native.LIB_PATH
+
+
+def test_capi_exports_every_declared_symbol(libpath):
+    import ctypes
+    hdr = open(os.path.join(ROOT, "include", "lds.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lds_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(libpath)
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    from lds import native
+    assert set(native.EXPORTS) <= declared
+    L.lds_last_error.restype = ctypes.c_char_p
+    assert L.lds_version() == 1
+    # argument validation happens before any device call
+    assert L.lds_unet_workspace_bytes(None, 1, 1, None) == -1
+    assert b"bad argument" in L.lds_last_error()
+
+
+def test_module_api_matches_reference_signatures():
+    from diffusion.diffusion import GaussianDiffusion
+    from diffusion.unit2mel import Unit2Mel, load_model_vocoder, load_svc_model
+    from diffusion.vocoder import Vocoder
+    sig = inspect.signature(Unit2Mel.__init__)
+    assert list(sig.parameters)[1:] == ["input_channel", "n_spk", "out_dims", "n_layers", "block_out_channels", "n_heads", "n_hidden",
+                                        "acoustic_scale"]
+    assert sig.parameters["out_dims"].default == 128 and sig.parameters["n_hidden"].default == 256
+    f = inspect.signature(Unit2Mel.forward)
+    assert list(f.parameters)[1:] == ["units", "volume", "spk_id", "aug_shift", "gt_spec", "infer", "infer_speedup", "method", "use_tqdm"]
+    assert f.parameters["method"].default == "unipc" and f.parameters["infer_speedup"].default == 10
+    g = inspect.signature(GaussianDiffusion.forward)
+    assert list(g.parameters)[1:] == ["condition", "gt_spec", "infer", "infer_speedup", "method", "k_step", "use_tqdm"]
+    assert g.parameters["method"].default == "dpm-solver"
+    assert list(inspect.signature(load_model_vocoder).parameters) == ["model_path", "device", "loaded_vocoder"]
+    assert list(inspect.signature(load_svc_model).parameters) == ["args", "vocoder_dimension"]
+    assert list(inspect.signature(Vocoder.__init__).parameters)[1:] == ["vocoder_type", "vocoder_ckpt", "device"]
+    with pytest.raises(ValueError):
+        Vocoder("nsf-hifigan", "nowhere", device="cpu")
+
+
+def test_no_cpu_fallback_on_the_product_path():
+    """the hot path must fail loudly, never silently compute on the CPU"""
+    import torch
+    from diffusion.diffusion import GaussianDiffusion
+    from diffusion.unet1d.unet_1d_condition import UNet1DConditionModel
+    from lds import native
+    boc = (64, 64)
+    unet = UNet1DConditionModel(in_channels=16 + 16, out_channels=16, block_out_channels=boc, norm_num_groups=8, cross_attention_dim=boc,
+                                attention_head_dim=2, only_cross_attention=True, layers_per_block=1, resnet_time_scale_shift="scale_shift")
+    gd = GaussianDiffusion(unet, out_dims=16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gd(torch.zeros(1, 8, 16), infer=True, infer_speedup=100, method="dpm-solver")
+    with pytest.raises(NotImplementedError):
+        gd(torch.zeros(1, 8, 16), infer=False)
+    with pytest.raises(RuntimeError):
+        native._dev(torch.zeros(4))
+    with pytest.raises(NotImplementedError):
+        UNet1DConditionModel(in_channels=8, out_channels=4, block_out_channels=boc, cross_attention_dim=boc, only_cross_attention=True,
+                             resnet_time_scale_shift="default")
+
+
+def test_diffusion_buffers_match_reference(golden):
+    from diffusion.diffusion import GaussianDiffusion
+    import torch
+    gd = GaussianDiffusion(torch.nn.Identity(), out_dims=80)
+    g = golden("schedule.npz")
+    sd = gd.state_dict()
+    for k, v in g.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+
+
+# ---- numpy interpreter of the coefficient tables, mirroring csrc/model.hip lds_sampler_run ----
+def _run_table(method, tab, eps_fn, x, noise=None):
+    f32 = np.float32
+    x = x.astype(f32)
+    B = x.shape[0]
+
+    def model(xx, t):
+        return eps_fn(xx, np.full((B,), t, dtype=f32))
+    m0 = m1 = None
+    if method == "dpm-solver":
+        for r in tab:
+            eps = model(x, r[0])
+            m1, m0 = m0, ((x - r[1] * eps) / r[2]).astype(f32)
+            if r[3] < 1.5:
+                x = (r[4] * x - r[5] * m0).astype(f32)
+            else:
+                x = (r[4] * x - r[5] * m0 - r[6] * (r[7] * (m0 - m1))).astype(f32)
+        return x
+    if method == "unipc":
+        eps = model(x, tab[0][0])
+        m0 = ((x - tab[0][1] * eps) / tab[0][2]).astype(f32)
+        for r in tab[1:]:
+            o2, corr = r[3] > 1.5, r[11] > 0.5
+            xt = (r[4] * x - r[5] * m0).astype(f32)
+            xp = (xt - r[6] * (r[8] * ((m1 - m0) / r[7]))).astype(f32) if o2 else xt
+            if corr:
+                eps = model(xp, r[0])
+                mt = ((xp - r[1] * eps) / r[2]).astype(f32)
+                if o2:
+                    x = (xt - r[6] * (r[9] * ((m1 - m0) / r[7]) + r[10] * (mt - m0))).astype(f32)
+                else:
+                    x = (xt - r[6] * (r[10] * (mt - m0))).astype(f32)
+                m1, m0 = m0, mt
+            else:
+                x = xp
+        return x
+    raise AssertionError(method)
+
+
+@pytest.mark.parametrize("S", [50, 20, 6, 2])
+def test_solver_tables_reproduce_reference_samplers(golden, S):
+    """product-side schedule/table code (diffusion/diffusion.py) + the table semantics of lds_sampler_run, against the
+    reference DPM_Solver / UniPC trajectories recorded with an analytic eps model"""
+    from diffusion.diffusion import dpm_table, unipc_table
+    from oracle import schedule
+    g = golden("solver_toy.npz")
+    betas = schedule.diffusion_buffers()["betas"]
+    cond = g["cond"]
+
+    def eps(xx, t_in):
+        return (np.float32(0.5) * np.sin(xx + t_in[:, None, None] * np.float32(0.001)) + np.float32(0.1) * cond[:, :80]).astype(np.float32)
+    x = g["xT"][:, 0]
+    y = _run_table("dpm-solver", dpm_table(betas, S), eps, x)
+    assert np.abs(y - g[f"dpm_{S}"][:, 0]).max() / np.abs(g[f"dpm_{S}"]).max() < 2e-6
+    y = _run_table("unipc", unipc_table(betas, S), eps, x)
+    assert np.abs(y - g[f"unipc_{S}"][:, 0]).max() / np.abs(g[f"unipc_{S}"]).max() < 2e-6
+
+
+def test_ddpm_ddim_plms_tables_match_oracle_coefficients():
+    from diffusion.diffusion import GaussianDiffusion
+    from oracle import schedule
+    import torch
+    gd = GaussianDiffusion(torch.nn.Identity(), out_dims=80)
+    b = schedule.diffusion_buffers()
+    tab = gd._ddpm_table(12)
+    assert tab.shape == (12, 16) and tab[0, 0] == 11 and tab[-1, 0] == 0 and tab[-1, 5] == 0.0
+    assert tab[3, 1] == b["sqrt_recip_alphas_cumprod"][8] and tab[3, 4] == b["posterior_mean_coef2"][8]
+    d = gd._ddim_table(1000, 100)
+    assert d.shape[0] == 10 and d[0, 0] == 900 and d[-1, 0] == 0
+    assert d[-1, 1] == d[-1, 2] and d[-1, 3] == 0.0          # the reference's identity last step (a_prev == a_t)
+    p = gd._plms_table(1000, 100)
+    assert p.shape[0] == 10 and p[0, 1] == 800 and p[-1, 1] == 0
+
+
+def test_seeded_initialiser_known_answers():
+    from lds import init_weights
+    v = init_weights.uniform("conv_in.weight", (4,), 0)
+    assert v.dtype == np.float32
+    # known answer: integer-only generator, so these bits are the same on every platform / numpy build
+    assert np.array_equal(v.view(np.uint32), np.array([0x3e11eb88, 0x3d8a9950, 0x3e5a0300, 0x3ed5ebf8], dtype=np.uint32))
+    a = init_weights.init_tensor("down_blocks.0.resnets.0.norm1.weight", (8,), 0)
+    assert ((a >= 0.8) & (a < 1.2)).all()
+    assert np.array_equal(init_weights.uniform("x", (5, 3), 3), init_weights.uniform("x", (15,), 3).reshape(5, 3))
+    assert not np.array_equal(init_weights.uniform("x", (8,), 3), init_weights.uniform("x", (8,), 4))
+
+
+def test_unit2mel_state_dict_keys_and_loading(tmp_path):
+    import torch
+    import yaml
+    from diffusion.unit2mel import Unit2Mel, load_svc_model, DotDict
+    from lds import arch
+    args = DotDict(yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "config_like_reference.yaml"))))
+    m = load_svc_model(args, 80)
+    assert isinstance(m, Unit2Mel) and m.n_spk == 323
+    exp = arch.unit2mel_param_shapes(1280, 323, arch.unet_config())
+    sd = m.state_dict()
+    assert set(sd) == set(exp) and all(tuple(sd[k].shape) == tuple(v) for k, v in exp.items())
+    # a checkpoint in the reference's format {'global_step', 'model'} round-trips through load_state_dict
+    torch.save({"global_step": 1, "model": sd}, tmp_path / "model_1.pt")
+    ck = torch.load(tmp_path / "model_1.pt", map_location="cpu")
+    m2 = load_svc_model(args, 80)
+    m2.load_state_dict(ck["model"])
+    assert m2._embed is None and m2.decoder.denoise_fn._native is None

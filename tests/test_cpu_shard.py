@@ -1,0 +1,62 @@
+"""The multi-GPU path on CPU: world_size-2 gloo processes exercise the utterance-batch scatter / gather used by
+bench.py (RCCL on the GPU box) and check shard-count invariance of the split."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG
+
+
+def test_shard_range_partitions():
+    import sys
+    sys.path.insert(0, PKG)
+    from lds.shard import shard_range
+    for n in (0, 1, 7, 16, 128, 129):
+        for w in (1, 2, 4, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n_items, q):
+    import sys
+    sys.path.insert(0, PKG)
+    from lds import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_items * 6, dtype=torch.float32).reshape(n_items, 2, 3) if rank == 0 else torch.empty(0)
+        mine = shard.scatter_batch(full, rank, world)
+        lo, hi = shard.shard_range(n_items, rank, world)
+        ref = torch.arange(n_items * 6, dtype=torch.float32).reshape(n_items, 2, 3)[lo:hi]
+        ok = torch.equal(mine, ref)
+        out = shard.gather_batch(mine * 2.0, rank, world)        # per-utterance work, then gather on rank 0
+        if rank == 0:
+            ok = ok and torch.equal(out, torch.arange(n_items * 6, dtype=torch.float32).reshape(n_items, 2, 3) * 2.0)
+        else:
+            ok = ok and out is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [8, 5])
+def test_scatter_gather_world2_gloo(n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_items
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
