@@ -17,25 +17,16 @@ def shard_range(n_items, rank, world):
 
 def scatter_batch(full, rank, world, src=0):
     """Rank `src` holds `full` [N, ...]; every rank returns its shard [n_r, ...].
-    Implemented as a broadcast of the shard sizes' common buffer + local slice when shards are
-    ragged, and as a true scatter when N % world == 0."""
+    One broadcast of the batch (RCCL broadcast over xGMI on the GPU box) + a local slice: the same code path for
+    even and ragged splits, and only collectives every backend implements."""
     if world == 1:
         return full
-    shape = [None]
-    if rank == src:
-        shape = [tuple(full.shape)]
+    shape = [tuple(full.shape) if rank == src else None]
     dist.broadcast_object_list(shape, src=src)
     shp = shape[0]
-    n = shp[0]
-    dev = full.device if full is not None else None
-    lo, hi = shard_range(n, rank, world)
-    if n % world == 0:
-        out = torch.empty((n // world,) + tuple(shp[1:]), dtype=torch.float32, device=dev)
-        chunks = list(full.contiguous().chunk(world)) if rank == src else None
-        dist.scatter(out, chunks, src=src)
-        return out
-    buf = full.contiguous() if rank == src else torch.empty(shp, dtype=torch.float32, device=dev)
+    buf = full.contiguous() if rank == src else torch.empty(shp, dtype=torch.float32, device=full.device)
     dist.broadcast(buf, src=src)
+    lo, hi = shard_range(shp[0], rank, world)
     return buf[lo:hi].contiguous()
 
 
