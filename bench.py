@@ -52,6 +52,26 @@ def cpu_baseline(T, n_eval):
             "sample": f"numpy oracle, 1 utterance x {T} frames, {n_eval}-NFE DPM-Solver++ run ({dt:.1f} s) scaled to 50 NFE"}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/*_hbm_traffic.json, produced by
+    tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if there is none."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    m = re.match(r"(\w+)<BM(\d+) BN(\d+) KT(\d+) S(\d+) U(\d+) BK(\d+)(?: NST(\d+))?>", kernel_name)
+    if not m:
+        return None
+    fam, bm, bn, kt, st, up, bk, nst = m.groups()
+    key = f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}>" if nst else None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        return ks[key]["hbm_bytes_per_launch"] if key in ks else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +178,8 @@ def main():
         conv_tf = sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12
         res["roofline"] = {
             "bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["name"]),
+            "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"],
             "launches": dom["count"], "avg_launch_us": 1e3 * dom["ms"] / dom["count"],
             "gflop_per_launch": dom["flops"] / dom["count"] / 1e9,
             "share_of_step_time": dom["ms"] / tot_ms,

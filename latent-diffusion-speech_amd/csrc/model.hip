@@ -300,6 +300,12 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     if (g_prof_on && !g_prof.empty() && g_prof.back().name == "conv_dma") {
         std::string cfgs(conv_dma_last_config());
         g_prof.back().name = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+        static const bool shapes = getenv("LDS_PROF_SHAPES") != nullptr;      // per-shape breakdown for tuning sessions
+        if (shapes) {
+            char sh[96];
+            snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "");
+            g_prof.back().name += sh;
+        }
     }
     if (e != hipSuccess)
         return fail(LDS_EHIP, "conv_dma launch failed (%s): Co %d Ci %d K %d stride %d ups %d To %d", hipGetErrorString(e), W.Co, W.Ci, W.K,
