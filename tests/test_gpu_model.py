@@ -119,3 +119,35 @@ def test_batch_shard_invariance_full_size(unit2mel_gpu):
     one = unet(x[2:3].contiguous(), t[2:3].contiguous()).sample
     assert torch.isfinite(full).all()
     assert torch.equal(full[2:3], one)
+
+
+def test_checkpoint_formats_and_facade(tmp_path, unit2mel_gpu, monkeypatch):
+    """reference on-disk formats end to end: <dir>/config.yaml + {'global_step','model'} .pt (tools/saver.py:85-109) and
+    decoder.pth = {'config': h, 'model': weight-norm state_dict} (hifi_vaegan.py:6-8,57-61), loaded through
+    load_model_vocoder / DiffusionSVC and run units -> wav."""
+    import os
+    import shutil
+    from conftest import ROOT
+    from lds import arch, init_weights
+    from tools.infer_tools import DiffusionSVC
+    h = arch.SYNTHETIC_VOCODER_H
+    vdir = tmp_path / "hifi-vaegan"
+    vdir.mkdir()
+    gstate = {k: torch.from_numpy(v) for k, v in init_weights.init_state(arch.generator_param_shapes(h), 0).items()}
+    torch.save({"config": h, "model": gstate}, vdir / "decoder.pth")
+    edir = tmp_path / "exp"
+    edir.mkdir()
+    cfg = open(os.path.join(ROOT, "tests", "golden", "config_like_reference.yaml")).read().replace("pretrain/hifi-vaegan", str(vdir))
+    (edir / "config.yaml").write_text(cfg)
+    torch.save({"global_step": 7, "model": {k: v.cpu() for k, v in unit2mel_gpu.state_dict().items()}}, edir / "model_7.pt")
+    svc = DiffusionSVC(device="cuda")
+    svc.load_model(str(edir / "model_7.pt"), f0_min=65, f0_max=800)
+    assert svc.vocoder.vocoder_hop_size == 512 and svc.vocoder.dimension == 80 and svc.vocoder.vocoder_sample_rate == 44100
+    B, T = 1, 16
+    units = dev(init_weights.uniform("facade.units", (B, T, 1280), 3, -1.7, 1.7))
+    xT = dev(init_weights.uniform("facade.xT", (B, 1, 80, T), 3, -1.7, 1.7))
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT)
+    wav = svc.infer(units, f0=None, volume=None, spk_id=5, infer_speedup=250, method="dpm-solver")
+    assert wav.shape == (B, 1, T * 512) and bool(torch.isfinite(wav).all())
+    mel = unit2mel_gpu(units, None, spk_id=torch.full((B, 1), 5, device="cuda"), infer=True, infer_speedup=250, method="dpm-solver")
+    assert torch.equal(svc.vocoder.infer(mel), wav)            # same weights through both loaders -> identical result
