@@ -24,12 +24,21 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     constexpr int DQ = D / 8;              // 8-channel blocks per head
     constexpr int DT = (D + 31) / 32;
     constexpr int KB = 64, VP = 68;
-    __shared__ __attribute__((aligned(16))) float Ks[DQ * 2 * KB * 4];   // [kq][h][key][4]
-    __shared__ __attribute__((aligned(16))) float Vs[DT * 32 * VP];      // [d][key], pitch 68
+    constexpr int KSZ = DQ * 2 * KB * 4, VSZ = DT * 32 * VP;
+    constexpr int NKL = DQ * 2 * KB / (NW * 64), NVL = D * (KB / 4) / (NW * 64);   // 16-byte entries per thread and tile
+    static_assert(NKL * NW * 64 == DQ * 2 * KB && NVL * NW * 64 == D * (KB / 4), "tile must split evenly over the threads");
+    __shared__ __attribute__((aligned(16))) float Ks[2 * KSZ];   // two stages of [kq][h][key][4]
+    __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ];   // two stages of [d][key], pitch 68
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y;
-    const int tq = blockIdx.x * (NW * 32) + wave * 32 + c;
+    // XCD-aware order: the query blocks of one (batch, head) share K and V, so they take consecutive slots of one XCD
+    // (workgroups are dispatched round-robin over the 8 XCDs, each with its own L2)
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const int id = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const int per = total >> 3, rem = total & 7, xcd = id & 7;
+    const int L = xcd * per + (xcd < rem ? xcd : rem) + (id >> 3);
+    const int qblk = L % gx, hd = (L / gx) % gy, b = L / (gx * gy);
+    const int tq = qblk * (NW * 32) + wave * 32 + c;
     const int Tp = T + 2;
     const float* qb = qk + ((long long)b * 2 * C + (long long)hd * D) * Tp;            // q rows of this head
     const float* kb = qk + ((long long)b * 2 * C + C + (long long)hd * D) * Tp;        // k rows
@@ -41,7 +50,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         qv[kq] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (tq < T) qv[kq] = *reinterpret_cast<const f32x4*>(qb + ((long long)(kq * 2 + h) * Tp + tq + 1) * 4);
     }
-    for (int i = tid; i < (DT * 32 - D) * VP; i += NW * 64) Vs[D * VP + i] = 0.f;      // head-dim padding rows (D = 48)
+    for (int i = tid; i < (DT * 32 - D) * VP; i += NW * 64) Vs[D * VP + i] = Vs[VSZ + D * VP + i] = 0.f;   // head-dim padding rows (D = 48)
 
     f32x16 o[DT];
 #pragma unroll
@@ -51,16 +60,18 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     float m_run = -INFINITY, l_run = 0.f;
     const bool vec = (T & 3) == 0;
 
-    for (int k0 = 0; k0 < T; k0 += KB) {
-        __syncthreads();
-        for (int idx = tid; idx < DQ * 2 * KB; idx += NW * 64) {          // K: straight 16-byte copies of K4P entries
-            const int row = idx / KB, key = idx - row * KB;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + key < T) v = *reinterpret_cast<const f32x4*>(kb + ((long long)row * Tp + k0 + key + 1) * 4);
-            *reinterpret_cast<f32x4*>(Ks + (row * KB + key) * 4) = v;
+    // software pipeline: the next key tile travels global -> registers while the current one is consumed from LDS
+    f32x4 kreg[NKL], vreg[NVL];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {                                   // K: straight 16-byte copies of K4P entries
+            const int idx = tid + i * NW * 64, row = idx / KB, key = idx - row * KB;
+            kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k0 + key < T) kreg[i] = *reinterpret_cast<const f32x4*>(kb + ((long long)row * Tp + k0 + key + 1) * 4);
         }
-        for (int idx = tid; idx < D * (KB / 4); idx += NW * 64) {         // V: rows of 64 keys
-            const int d = idx / (KB / 4), j = (idx - d * (KB / 4)) * 4;
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {                                   // V: rows of 64 keys
+            const int idx = tid + i * NW * 64, d = idx / (KB / 4), j = (idx - d * (KB / 4)) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (vec && k0 + j + 3 < T) {
                 v = *reinterpret_cast<const f32x4*>(vb + (long long)d * T + k0 + j);
@@ -68,9 +79,31 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (k0 + j + e < T) ? vb[(long long)d * T + k0 + j + e] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(Vs + d * VP + j) = v;
+            vreg[i] = v;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + i * NW * 64;
+            *reinterpret_cast<f32x4*>(Ks + stage * KSZ + idx * 4) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + i * NW * 64, d = idx / (KB / 4), j = (idx - d * (KB / 4)) * 4;
+            *reinterpret_cast<f32x4*>(Vs + stage * VSZ + d * VP + j) = vreg[i];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    int stage = 0;
+    for (int k0 = 0; k0 < T; k0 += KB, stage ^= 1) {
+        const bool more = k0 + KB < T;
+        if (more) fetch(k0 + KB);
+        const float* Kc = Ks + stage * KSZ;
+        const float* Vc = Vs + stage * VSZ;
 #pragma unroll 1
         for (int kt = 0; kt < KB / 32; ++kt) {
             const int kbase = k0 + kt * 32;
@@ -80,7 +113,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int kq = 0; kq < DQ; ++kq) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(Ks + ((kq * 2 + h) * KB + kt * 32 + c) * 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(Kc + ((kq * 2 + h) * KB + kt * 32 + c) * 4);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], qv[kq][jj], s, 0, 0, 0);
             }
@@ -112,12 +145,14 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(Vs + (i * 32 + c) * VP + kt * 32 + 8 * g + 4 * h);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(Vc + (i * 32 + c) * VP + kt * 32 + 8 * g + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], s[4 * g + e], o[i], 0, 0, 0);
                 }
             }
         }
+        if (more) stash(stage ^ 1);       // that stage was last read one iteration ago, before the barrier below
+        __syncthreads();
     }
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     if (tq < T) {

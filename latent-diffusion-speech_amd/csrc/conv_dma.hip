@@ -68,6 +68,7 @@ struct DmaKernel {
     int bcol[TN];
     f32x16 acc[NACC][TM][TN];
     f32x4 aop[NB][TM], bop[NB][TN];
+    float lmu[TN], lrs[TN];   // folded input-LayerNorm statistics of this lane's output columns
 
     __device__ __forceinline__ DmaKernel(const DmaConvArgs& p_, float* s_) : p(p_), smem(s_) {}
 
@@ -77,10 +78,19 @@ struct DmaKernel {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         c = lane & 31; h = lane >> 5;
         wm = wave >> 1; wn = wave & 1;
+        // XCD-aware tile order.  Workgroups are dispatched in linear order, round-robin over the 8 XCDs, each with a private
+        // L2.  The workgroups that read the same activation window (all M-blocks of one (batch, frame-block)) are given
+        // consecutive slots of ONE XCD, so the window is fetched from the fabric once instead of once per XCD.
         const int nMb = p.Mp / BM;
-        const int mb = blockIdx.x % nMb;          // M fastest: neighbouring blocks share the activation tile (L2)
-        const int nb = blockIdx.x / nMb;
-        b = blockIdx.y;
+        const int gx = gridDim.x, total = gx * gridDim.y;
+        const int id = blockIdx.y * gx + blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3, per = total >> 3, rem = total & 7;
+        const int L = xcd * per + (xcd < rem ? xcd : rem) + slot;
+        const int mb = L % nMb;                   // M fastest: neighbours share the activation tile
+        const int tb = L / nMb;
+        const int nN = gx / nMb;
+        const int nb = tb % nN;
+        b = tb / nN;
         m0 = mb * BM; t0 = nb * BN;
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
@@ -171,10 +181,42 @@ struct DmaKernel {
         }
     }
 
+    // LayerNorm over the input channels (reference attention.py:83,102,118), folded into the epilogue: per output column
+    // combine the producer's per-32-channel (mean, M2) partials in a fixed order (Chan).  Called right after the first
+    // tiles' DMAs are issued; the partials are fetched eight at a time so the loads overlap instead of forming a chain
+    // of dependent round trips.
+    __device__ __forceinline__ void ln_columns() {
+        constexpr int CH = 8;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = t0 + wn * TN * 32 + j * 32 + c;
+            const bool ok = n < p.To;
+            const float2* src = p.ln_part + (long long)b * p.ln_np * p.Tsrc + (ok ? n : 0);
+            float mean = 0.f, m2 = 0.f, cnt = 0.f;
+            for (int q0 = 0; q0 < p.ln_np; q0 += CH) {
+                float2 pr[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) pr[e] = src[(long long)((q0 + e < p.ln_np) ? q0 + e : q0) * p.Tsrc];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    if (q0 + e < p.ln_np) {
+                        const float d = pr[e].x - mean, nn = cnt + 32.f;
+                        mean += d * (32.f * __builtin_amdgcn_rcpf(nn));     // nn = 32 * k: the quotient 1/k rounds the same in rcp
+                        m2 += pr[e].y + d * d * (cnt * 32.f * __builtin_amdgcn_rcpf(nn));
+                        cnt = nn;
+                    }
+                }
+            }
+            lmu[j] = mean;
+            lrs[j] = ok ? 1.0f / sqrtf(m2 / cnt + p.ln_eps) : 0.f;
+        }
+    }
+
     __device__ __forceinline__ void mainloop() {
         constexpr int AHEAD = NST - 1;
         const int nk = p.Ci / BK;
         for (int t = 0; t < AHEAD && t < nk; ++t) issue_tile(t, smem + t * STAGE);
+        if (p.ln_part) ln_columns();
         int sc = 0, sn = AHEAD % NST;
         for (int kc = 0; kc < nk; ++kc) {
             // this wave's share of tile kc has landed when at most the younger tiles' DMAs are outstanding
@@ -192,64 +234,112 @@ struct DmaKernel {
         }
     }
 
-    // value of output register r of tile (i, j) after bias / GEGLU
-    __device__ __forceinline__ float outval(int i, int j, int r, bool geglu) const {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // packed weight row
-        float v = (NACC == 2) ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] : acc[0][i][j][r];
-        if (geglu) {
-            float g = acc[0][TM - 1][j][r];
-            if (p.bias) { v += p.bias[m]; g += p.bias[m + 32]; }
-            v = v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
-        } else if (p.bias) {
-            v += p.bias[m];
+    // Epilogue, phase 1: accumulators -> output values in place (acc[0]).  All loads of a phase are issued before their
+    // first use and before any store: a load placed after a store cannot be moved above it (possible aliasing), and a
+    // load -> wait -> store chain costs one memory round trip per element.
+    __device__ __forceinline__ void finalize(bool geglu) {
+        if constexpr (NACC == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[0][i][j] += acc[1][i][j];
         }
-        return v;
+        const bool ln = p.ln_part != nullptr;
+        if (ln || p.bias) {
+            float k1[TM][16], k2[TM][16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // packed weight row
+                    k1[i][r] = ln ? p.ln_c1[m] : 0.f;
+                    k2[i][r] = ln ? p.ln_c2[m] : p.bias[m];
+                }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[0][i][j][r];
+                        acc[0][i][j][r] = ln ? lrs[j] * (v - lmu[j] * k1[i][r]) + k2[i][r] : v + k2[i][r];
+                    }
+        }
+        if (geglu) {      // rows of tile 0 are the values, rows of tile 1 the gates (pack_geglu)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = acc[0][TM - 1][j][r];
+                    acc[0][0][j][r] *= 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+                }
+        }
     }
 
     // frame-major store of one 32x32 tile: out[b][co][n], co = c0 + local row
-    __device__ __forceinline__ void store_plain(float* base, int Cn, int c0, int i, int j, int n, bool geglu) {
+    __device__ __forceinline__ void store_plain(float* base, int Cn, int c0, int i, int j, int n) {
         if (n >= p.To) return;
         float* ob = base + ((long long)b * Cn + c0) * p.To + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (c0 + rl < Cn) ob[rl * p.To] = outval(i, j, r, geglu);
+            if (c0 + rl < Cn) ob[rl * p.To] = acc[0][i][j][r];
         }
     }
 
-    // K4P store of one 32x32 tile (+ residual, + pad frames, + LayerNorm partials).  Registers (4g+hh, 4g+2+hh) of this
-    // lane are elements (2h, 2h+1) of row (q = tile0/8 + g, hh): two 8-byte stores per 8-channel block; the two lane
-    // halves together fill the 16-byte entry, and consecutive lanes are consecutive frames.
-    __device__ __forceinline__ void store_k4p(int tile0, int i, int j, int n, bool geglu) {
+    // K4P addressing of one 32x32 tile.  Registers (4g+hh, 4g+2+hh) of this lane are elements (2h, 2h+1) of row
+    // (q = tile0/8 + g, hh): two 8-byte accesses per 8-channel block; the two lane halves together fill the 16-byte entry,
+    // and consecutive lanes are consecutive frames.
+    __device__ __forceinline__ int k4p_off(int tile0, int n) const { return (((tile0 >> 3) * 2) * (p.To + 2) + n + 1) * 4 + 2 * h; }
+    __device__ __forceinline__ int k4p_ck() const { return (p.plain_from < p.Cout) ? p.plain_from : p.Cout; }
+
+    // phase 2: residual add (all loads in flight together, before any store)
+    __device__ __forceinline__ void add_residual(int tile0, int i, int j, int n) {
+        if (n >= p.To) return;
         const int Tpo = p.To + 2;
-        const int Ck = (p.plain_from < p.Cout) ? p.plain_from : p.Cout;
-        float* ob = p.out + (long long)b * Ck * Tpo;
-        const float* rb = p.res ? p.res + (long long)b * Ck * Tpo : nullptr;
-        const bool ok = n < p.To;
-        int off = (((tile0 >> 3) * 2) * Tpo + n + 1) * 4 + 2 * h;       // row (q0, hh=0); +Tpo*4 per row
-        float s1 = 0.f, vals[16];
+        const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
+        f32x2 rv[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int e = 0; e < 8; ++e) rv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                f32x2 v = {outval(i, j, 4 * g + hh, geglu), outval(i, j, 4 * g + 2 + hh, geglu)};
-                if (ok) {
-                    if (rb) v += *reinterpret_cast<const f32x2*>(rb + off);
-                    *reinterpret_cast<f32x2*>(ob + off) = v;
-                    if (n == 0) *reinterpret_cast<f32x2*>(ob + off - 4) = f32x2{0.f, 0.f};          // left pad frame
-                    if (n == p.To - 1) *reinterpret_cast<f32x2*>(ob + off + 4) = f32x2{0.f, 0.f};   // right pad frame
-                }
-                vals[4 * g + hh] = v[0]; vals[4 * g + 2 + hh] = v[1];
-                s1 += v[0] + v[1];
-                off += Tpo * 4;
+                acc[0][i][j][4 * g + hh] += rv[2 * g + hh][0];
+                acc[0][i][j][4 * g + 2 + hh] += rv[2 * g + hh][1];
+            }
+    }
+
+    // phase 3: K4P store of one 32x32 tile (+ pad frames, + LayerNorm partials)
+    __device__ __forceinline__ void store_k4p(int tile0, int i, int j, int n) {
+        const int Tpo = p.To + 2;
+        const int Ck = k4p_ck();
+        const bool ok = n < p.To;
+        float* ob = p.out + (long long)b * Ck * Tpo + k4p_off(tile0, n);
+        if (ok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    *reinterpret_cast<f32x2*>(ob + (2 * g + hh) * Tpo * 4) = f32x2{acc[0][i][j][4 * g + hh], acc[0][i][j][4 * g + 2 + hh]};
+            if (n == 0) {                     // left pad frame
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 - 4) = f32x2{0.f, 0.f};
+            }
+            if (n == p.To - 1) {              // right pad frame
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 + 4) = f32x2{0.f, 0.f};
             }
         }
         if (p.lnpart_out) {
-            // per-frame (mean, M2) over this tile's 32 channels -> LayerNorm partials (combined by ln_apply)
+            // per-frame (mean, M2) over this tile's 32 channels -> LayerNorm partials (combined by the consumer, ln_columns)
+            float s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1 += acc[0][i][j][r];
             const float m16 = s1 * (1.0f / 16.0f);
             float qv = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = vals[r] - m16; qv += d * d; }
+            for (int r = 0; r < 16; ++r) { const float d = acc[0][i][j][r] - m16; qv += d * d; }
             const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(qv, 32, 64);
             const float d = mo - m16;
             if (h == 0 && ok)
@@ -257,18 +347,35 @@ struct DmaKernel {
         }
     }
 
+    __device__ __forceinline__ int tile_ch(int i, bool geglu) const {      // first output channel of tile row i
+        return geglu ? (m0 + wm * 64) / 2 : (m0 + wm * TM * 32 + i * 32);
+    }
+
     __device__ __forceinline__ void epilogue() {
         const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
+        finalize(geglu);
+        const int ni = geglu ? 1 : TM;
+        if (p.res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i >= ni) break;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int tile0 = tile_ch(i, geglu);
+                    if (!p.out_plain && tile0 < p.plain_from && tile0 < p.Cout) add_residual(tile0, i, j, t0 + wn * TN * 32 + j * 32 + c);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (geglu && i == 1) break;
+            if (i >= ni) break;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
-                const int tile0 = geglu ? (m0 + wm * 64) / 2 : (m0 + wm * TM * 32 + i * 32);   // first output channel of this tile
-                if (p.out_plain) store_plain(p.out, p.Cout, tile0, i, j, n, geglu);
-                else if (tile0 >= p.plain_from) store_plain(p.out2, p.Cout - p.plain_from, tile0 - p.plain_from, i, j, n, geglu);
-                else if (tile0 < p.Cout) store_k4p(tile0, i, j, n, geglu);
+                const int tile0 = tile_ch(i, geglu);
+                if (p.out_plain) store_plain(p.out, p.Cout, tile0, i, j, n);
+                else if (tile0 >= p.plain_from) store_plain(p.out2, p.Cout - p.plain_from, tile0 - p.plain_from, i, j, n);
+                else if (tile0 < p.Cout) store_k4p(tile0, i, j, n);
             }
         }
     }

@@ -161,63 +161,6 @@ hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int
     return hipGetLastError();
 }
 
-// ---- LayerNorm over channels: block = (64 frames) x (32-channel tile) of one batch element; every block combines the
-//      producer's per-32-channel partials of its frames (Chan, fixed order), then streams its 8 K4P rows ----
-__global__ void __launch_bounds__(256) ln_apply_kernel(const float* __restrict__ x, const float2* __restrict__ part, int C, int T, float eps,
-                                                       const float4* __restrict__ gb, float* __restrict__ y) {
-    __shared__ float smean[64], srstd[64];
-    const int b = blockIdx.z, ct = blockIdx.y, t0 = blockIdx.x * 64;
-    const int Tp = T + 2, np = C >> 5;
-    if (threadIdx.x < 64) {
-        const int t = t0 + threadIdx.x;
-        float mean = 0.f, m2 = 0.f, n = 0.f;
-        if (t < T) {
-            for (int i = 0; i < np; ++i) {
-                const float2 pr = part[((long long)b * np + i) * T + t];
-                const float d = pr.x - mean, nn = n + 32.f;
-                mean += d * (32.f / nn);
-                m2 += pr.y + d * d * (n * 32.f / nn);
-                n = nn;
-            }
-        }
-        smean[threadIdx.x] = mean;
-        srstd[threadIdx.x] = (t < T) ? 1.0f / sqrtf(m2 / n + eps) : 0.f;
-    }
-    const int tl = threadIdx.x & 63, rsel = threadIdx.x >> 6;      // 4 row slots x 64 frames; 8 rows per tile -> 2 rows per thread
-    const int t = t0 + tl;
-    float ga[2][4], be[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int row = ct * 8 + rsel + 4 * k, q = row >> 1, hh = row & 1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float4 g = gb[q * 8 + 2 * j + hh]; ga[k][j] = g.x; be[k][j] = g.y; }
-    }
-    __syncthreads();
-    const float mu = smean[tl], rs = srstd[tl];
-    const float* xb = x + (long long)b * C * Tp;
-    float* yb = y + (long long)b * C * Tp;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int row = ct * 8 + rsel + 4 * k;                  // row = q*2 + hh
-        if (t < T) {
-            const long long off = ((long long)row * Tp + t + 1) * 4;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + off);
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (xv[j] - mu) * (rs * ga[k][j]) + be[k][j];
-            *reinterpret_cast<f32x4*>(yb + off) = v;
-        }
-        if (t == 0) *reinterpret_cast<f32x4*>(yb + ((long long)row * Tp) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t == T - 1) *reinterpret_cast<f32x4*>(yb + ((long long)row * Tp + T + 1) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
-hipError_t launch_ln_apply(const float* x, const float2* part, int C, int T, float eps, const float4* gb, float* y, int B, hipStream_t s) {
-    if (C & 31) return hipErrorInvalidValue;
-    ProfScope ps(s, "ln_apply", 0.0, 4.0 * 2.0 * B * (double)C * T);
-    hipLaunchKernelGGL(ln_apply_kernel, dim3((T + 63) / 64, C / 32, B), dim3(256), 0, s, x, part, C, T, eps, gb, y);
-    return hipGetLastError();
-}
-
 __global__ void __launch_bounds__(256) resample_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int Tin, int Tout) {
     const long long row = blockIdx.x;                // (b, q, hh) flattened
     const float sc = (float)Tin / (float)Tout;

@@ -73,6 +73,10 @@ struct DmaConvArgs {
     int out_plain;
     int plain_from; float* out2;        // output channels >= plain_from go frame-major to out2 [B][Cout-plain_from][To]
     float2* lnpart_out;                 // optional [B][C/32][To] per-frame (mean, M2) partials over 32-channel tiles
+    // LayerNorm of the INPUT folded into the epilogue (weights pre-multiplied by gamma on the host):
+    //   y[m,t] = rstd_t * (acc[m,t] - mean_t * ln_c1[m]) + ln_c2[m],  c1 = sum_c W[m,c]*gamma_c,  c2 = sum_c W[m,c]*beta_c + bias[m]
+    // mean_t / rstd_t are combined per column from the producer's partials ln_part [B][ln_np][Tsrc]
+    const float2* ln_part; int ln_np; float ln_eps; const float* ln_c1; const float* ln_c2;
     int Cout, To, B;
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
@@ -91,9 +95,6 @@ hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hip
 hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps,
                            const float* gamma, const float* beta, const float* scale_shift, int ss_stride, int ss_off,
                            int silu, float4* part, float* y, int B, hipStream_t s);
-// LayerNorm over channels from the producer's 32-channel partials: y = (x - mean_t) * rstd_t * gamma + beta (K4P -> K4P)
-hipError_t launch_ln_apply(const float* x, const float2* part, int C, int T, float eps, const float4* gamma_beta, float* y, int B,
-                           hipStream_t s);
 // nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
 hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
 // self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v frame-major [B][C][T]; out K4P [B][C][T]

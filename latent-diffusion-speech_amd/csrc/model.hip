@@ -174,6 +174,31 @@ static bool pack_geglu(Owner& o, const float* w, const float* b, int C8, int Ci,
     return out.w && out.bias;
 }
 
+// LayerNorm folded into a following linear layer: weights pre-multiplied by gamma, plus the two per-row constants of
+// DmaConvArgs (c1 = sum_c W*gamma, c2 = sum_c W*beta + bias).  `perm[m]` = source row of packed row m.
+static bool pack_ln_fold(Owner& o, const float* w, const float* b, const float* gamma, const float* beta, int Co, int Ci,
+                         const std::vector<int>& perm, ConvW& out, float*& c1_out, float*& c2_out) {
+    const int Mp = round_mp(Co);
+    std::vector<float> p((size_t)Ci * Mp, 0.f), c1(Mp, 0.f), c2(Mp, 0.f);
+    for (int m = 0; m < Co; ++m) {
+        const int src = perm.empty() ? m : perm[m];
+        double s1 = 0, s2 = b ? (double)b[src] : 0.0;
+        for (int ci = 0; ci < Ci; ++ci) {
+            const float wg = w[(size_t)src * Ci + ci] * gamma[ci];
+            p[widx(0, ci, m, Ci, Mp)] = wg;
+            s1 += (double)wg;
+            s2 += (double)w[(size_t)src * Ci + ci] * (double)beta[ci];
+        }
+        c1[m] = (float)s1; c2[m] = (float)s2;
+    }
+    out.w = o.upload(p);
+    out.bias = nullptr;
+    out.Co = Co; out.Ci = Ci; out.K = 1; out.Mp = Mp;
+    c1_out = o.upload(c1);
+    c2_out = o.upload(c2);
+    return out.w && c1_out && c2_out;
+}
+
 // ConvTranspose1d (reference models.py:233-236) as `stride` interleaved phase filters of K/stride taps:
 // packed[tap][ci][co*stride + phi] = w[ci][co][phi + stride*(KT-1-tap)]
 static bool pack_convT(Owner& o, const float* w, const float* b, int Ci, int Co, int K, int stride, ConvW& out) {
@@ -273,6 +298,7 @@ struct DOpt {
     int epi = EPI_NONE, out_plain = 0, plain_from = -1;
     float* out2 = nullptr;
     float2* lnpart_out = nullptr;
+    const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
 };
 static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B,
@@ -287,6 +313,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     a.Cout = (o.epi == EPI_GEGLU) ? W.Co / 2 : W.Co;
     a.plain_from = (o.plain_from >= 0) ? o.plain_from : a.Cout;
     a.out2 = o.out2; a.lnpart_out = o.lnpart_out;
+    a.ln_part = o.ln_part; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.ln_c1 = o.ln_c1; a.ln_c2 = o.ln_c2;
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
     a.To = (Tin + 2 * o.pad - (W.K - 1) - 1) / o.stride + 1;
     a.B = B;
@@ -326,7 +353,7 @@ struct ResnetW {
 struct TfmW {
     int C = 0;
     float *gn_g = nullptr, *gn_b = nullptr;
-    float4* ln_gb[3] = {nullptr, nullptr, nullptr};   // LayerNorm {gamma, beta, 0, 0} per channel
+    float *qkv_c1[2] = {nullptr, nullptr}, *qkv_c2[2] = {nullptr, nullptr}, *ff1_c1 = nullptr, *ff1_c2 = nullptr;   // folded LayerNorm constants
     ConvW proj_in, proj_out, qkv[2], o[2], ff1, ff2;
 };
 struct DownBlk { std::vector<ResnetW> res; std::vector<TfmW> att; bool has_down = false; ConvW down; int ch = 0; };
@@ -396,15 +423,12 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
     if (!t.gn_g || !t.gn_b || !piw || !pib || !pow_ || !pob) return false;
     if (!pack_conv(o, piw, pib, C, C, 1, t.proj_in) || !pack_conv(o, pow_, pob, C, C, 1, t.proj_out)) return false;
     const std::string b = p + "transformer_blocks.0.";
+    const float *lg[3], *lb[3];
     for (int i = 0; i < 3; ++i) {
         const std::string n = b + "norm" + std::to_string(i + 1);
-        const float* g = T.get(n + ".weight", C);
-        const float* be = T.get(n + ".bias", C);
-        if (!g || !be) return false;
-        std::vector<float> gb((size_t)4 * C, 0.f);
-        for (int c = 0; c < C; ++c) { gb[4 * c] = g[c]; gb[4 * c + 1] = be[c]; }
-        t.ln_gb[i] = (float4*)o.upload(gb);
-        if (!t.ln_gb[i]) return false;
+        lg[i] = T.get(n + ".weight", C);
+        lb[i] = T.get(n + ".bias", C);
+        if (!lg[i] || !lb[i]) return false;
     }
     for (int i = 0; i < 2; ++i) {
         const std::string a = b + "attn" + std::to_string(i + 1) + ".";
@@ -418,7 +442,8 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
         memcpy(cat.data(), q, sizeof(float) * C * C);
         memcpy(cat.data() + (size_t)C * C, k, sizeof(float) * C * C);
         memcpy(cat.data() + (size_t)2 * C * C, v, sizeof(float) * C * C);
-        if (!pack_conv(o, cat.data(), nullptr, 3 * C, C, 1, t.qkv[i])) return false;
+        // norm{1,2} (LayerNorm) is folded into the bias-free q/k/v projection
+        if (!pack_ln_fold(o, cat.data(), nullptr, lg[i], lb[i], 3 * C, C, {}, t.qkv[i], t.qkv_c1[i], t.qkv_c2[i])) return false;
         if (!pack_conv(o, ow, ob, C, C, 1, t.o[i])) return false;
     }
     const float* f1 = T.get(b + "ff.net.0.proj.weight", (int64_t)8 * C * C);
@@ -426,7 +451,12 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
     const float* f2 = T.get(b + "ff.net.2.weight", (int64_t)C * 4 * C);
     const float* f2b = T.get(b + "ff.net.2.bias", C);
     if (!f1 || !f1b || !f2 || !f2b) return false;
-    if (!pack_geglu(o, f1, f1b, 8 * C, C, t.ff1)) return false;
+    {
+        // norm3 folded into the GEGLU projection; rows interleaved value/gate in 32-row groups as in pack_geglu
+        std::vector<int> perm(8 * C);
+        for (int mm = 0; mm < 8 * C; ++mm) perm[mm] = ((mm % 64) / 32 == 0 ? 0 : 4 * C) + 32 * (mm / 64) + mm % 32;
+        if (!pack_ln_fold(o, f1, f1b, lg[2], lb[2], 8 * C, C, perm, t.ff1, t.ff1_c1, t.ff1_c2)) return false;
+    }
     if (!pack_conv(o, f2, f2b, C, 4 * C, 1, t.ff2)) return false;
     return true;
 }
@@ -663,20 +693,20 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
-        HIP_TRY(launch_ln_apply(h, w.lnp, C, T, 1e-5f, t.ln_gb[a], w.lnb, B, st));
         DOpt oq;
         oq.plain_from = 2 * C; oq.out2 = w.v;                      // q, k in K4P; v frame-major for the P.V operand reads
-        LDS_TRY(run_dconv(t.qkv[a], w.lnb, C, nullptr, 0, T, oq, w.qk, B, st));
+        oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
+        LDS_TRY(run_dconv(t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
         HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
         DOpt oo;
         oo.res = h; oo.lnpart_out = w.lnp;
         LDS_TRY(run_dconv(t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
         float* tmp = h; h = hn; hn = tmp;
     }
-    HIP_TRY(launch_ln_apply(h, w.lnp, C, T, 1e-5f, t.ln_gb[2], w.lnb, B, st));
     DOpt of;
     of.epi = EPI_GEGLU;
-    LDS_TRY(run_dconv(t.ff1, w.lnb, C, nullptr, 0, T, of, w.ff, B, st));
+    of.ln_part = w.lnp; of.ln_np = C / 32; of.ln_c1 = t.ff1_c1; of.ln_c2 = t.ff1_c2;
+    LDS_TRY(run_dconv(t.ff1, h, C, nullptr, 0, T, of, w.ff, B, st));
     DOpt o2;
     o2.res = h;
     LDS_TRY(run_dconv(t.ff2, w.ff, 4 * C, nullptr, 0, T, o2, hn, B, st));
@@ -1331,30 +1361,27 @@ extern "C" int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C
     return LDS_OK;
 }
 
-// mid = w1 * x (1x1, emits LayerNorm partials); out = w2 * LayerNorm_C(mid) with the LayerNorm materialised by ln_apply
+// mid = w1 * x (1x1, emits LayerNorm partials); out = w2 * LayerNorm_C(mid) with the LayerNorm folded into conv2's epilogue
 extern "C" int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
                                      float* mid, float* out, int B, int C, int Co, int T, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     Owner own;
     TmpDev tmp;
     ConvW W1, W2;
-    if (!pack_conv(own, w1, nullptr, C, C, 1, W1) || !pack_conv(own, w2, nullptr, Co, C, 1, W2)) return fail(LDS_ENOMEM, "upload failed");
-    std::vector<float> gbv((size_t)4 * C, 0.f);
-    for (int c = 0; c < C; ++c) { gbv[4 * c] = gamma[c]; gbv[4 * c + 1] = beta[c]; }
-    float4* dgb = (float4*)own.upload(gbv);
+    float *c1 = nullptr, *c2 = nullptr;
+    if (!pack_conv(own, w1, nullptr, C, C, 1, W1) || !pack_ln_fold(own, w2, nullptr, gamma, beta, Co, C, {}, W2, c1, c2)) return fail(LDS_ENOMEM, "upload failed");
     float* kx = tmp.f((size_t)B * C * (T + 2));
     float* km = tmp.f((size_t)B * C * (T + 2));
-    float* kn = tmp.f((size_t)B * C * (T + 2));
     float* ko = tmp.f((size_t)B * Co * (T + 2));
     float* part = tmp.f((size_t)B * (C / 32) * T * 2);
-    if (!dgb || !kx || !km || !kn || !ko || !part) return fail(LDS_ENOMEM, "alloc");
+    if (!kx || !km || !ko || !part) return fail(LDS_ENOMEM, "alloc");
     HIP_TRY(launch_to_k4p(x, kx, B, C, T, C, 0, st));
     DOpt o1;
     o1.lnpart_out = (float2*)part;
     LDS_TRY(run_dconv(W1, kx, C, nullptr, 0, T, o1, km, B, st));
-    HIP_TRY(launch_ln_apply(km, (const float2*)part, C, T, eps, dgb, kn, B, st));
     DOpt o2;
-    LDS_TRY(run_dconv(W2, kn, C, nullptr, 0, T, o2, ko, B, st));
+    o2.ln_part = (const float2*)part; o2.ln_np = C / 32; o2.ln_eps = eps; o2.ln_c1 = c1; o2.ln_c2 = c2;
+    LDS_TRY(run_dconv(W2, km, C, nullptr, 0, T, o2, ko, B, st));
     HIP_TRY(launch_from_k4p(km, mid, B, C, T, st));
     HIP_TRY(launch_from_k4p(ko, out, B, Co, T, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -146,7 +146,7 @@ def test_checkpoint_formats_and_facade(tmp_path, unit2mel_gpu, monkeypatch):
     B, T = 1, 16
     units = dev(init_weights.uniform("facade.units", (B, T, 1280), 3, -1.7, 1.7))
     xT = dev(init_weights.uniform("facade.xT", (B, 1, 80, T), 3, -1.7, 1.7))
-    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT)
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT.clone())      # the sampler updates x in place
     wav = svc.infer(units, f0=None, volume=None, spk_id=5, infer_speedup=250, method="dpm-solver")
     assert wav.shape == (B, 1, T * 512) and bool(torch.isfinite(wav).all())
     mel = unit2mel_gpu(units, None, spk_id=torch.full((B, 1), 5, device="cuda"), infer=True, infer_speedup=250, method="dpm-solver")
