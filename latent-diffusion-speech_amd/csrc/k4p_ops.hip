@@ -8,6 +8,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace lds {
 
@@ -104,12 +105,19 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     const int bpg = nq / groups;                     // 8-channel blocks per group
     const int g0 = (q / bpg) * bpg;
     float mean = 0.f, m2 = 0.f, n = 0.f;
-    for (int i = 0; i < bpg; ++i) {                  // Chan's parallel combination, fixed order
-        const float4 pp = part[(long long)b * nq + g0 + i];
-        const float d = pp.x - mean, nn = n + pp.z;
-        mean += d * (pp.z / nn);
-        m2 += pp.y + d * d * (n * pp.z / nn);
-        n = nn;
+    for (int i0 = 0; i0 < bpg; i0 += 8) {            // Chan's parallel combination, fixed order; partials fetched 8 at a time
+        float4 pp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pp[e] = part[(long long)b * nq + g0 + ((i0 + e < bpg) ? i0 + e : i0)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (i0 + e < bpg) {
+                const float d = pp[e].x - mean, nn = n + pp[e].z;
+                mean += d * (pp[e].z / nn);
+                m2 += pp[e].y + d * d * (n * pp[e].z / nn);
+                n = nn;
+            }
+        }
     }
     const float rstd = 1.0f / sqrtf(m2 / n + eps);
     // per-channel coefficients of this block: v = (x - mean) * a + bb
@@ -146,11 +154,120 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     }
 }
 
+// ---- GroupNorm in ONE pass over memory: one 1024-thread workgroup per (batch, group) keeps the whole group
+//      ((C/groups) channels x T frames, <= MAXI 16-byte entries per thread) in registers: exact two-pass statistics
+//      (mean, then sum of squared deviations) from the registers, then normalise + affine (+scale/shift) (+SiLU) and
+//      write.  All of a thread's loads are issued before the first use.  Sums are combined in a fixed order. ----
+template <int MAXI>
+__global__ void __launch_bounds__(1024) gn_fused_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
+                                                        int groups, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ ss, int ss_stride,
+                                                        int ss_off, int silu, float* __restrict__ y) {
+    constexpr int NT = 1024, MAXR = 64;
+    __shared__ float red[NT / 64];
+    __shared__ __attribute__((aligned(16))) float cA[MAXR * 4], cB[MAXR * 4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
+    const int bpg = nq / groups, R = 2 * bpg;      // rows (block, hh) of Tp entries each
+    const int dq = NT / Tp, dr = NT - dq * Tp;
+    // per-channel affine terms of row tid>>2, element tid&3 (fetched early; finished once the statistics are known)
+    float ga = 0.f, be = 0.f, sc = 1.f, sh = 0.f;
+    if (tid < R * 4) {
+        const int row = tid >> 2, ci = (g * bpg + (row >> 1)) * 8 + 2 * (tid & 3) + (row & 1);
+        ga = gamma[ci]; be = beta[ci];
+        if (ss) {
+            sc = 1.0f + ss[(long long)b * ss_stride + ss_off + ci];
+            sh = ss[(long long)b * ss_stride + ss_off + C + ci];
+        }
+    }
+    f32x4 v[MAXI];
+    {
+        int row = tid / Tp, e = tid - row * Tp;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < R && e >= 1 && e <= T) {
+                const int q = g * bpg + (row >> 1);
+                const float* src = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2 + (row & 1)) * Tp * 4
+                                             : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2 + (row & 1)) * Tp * 4;
+                v[i] = *reinterpret_cast<const f32x4*>(src + (long long)e * 4);
+            }
+            row += dq; e += dr;
+            if (e >= Tp) { e -= Tp; ++row; }
+        }
+    }
+    const float n = (float)(C / groups) * (float)T;
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);      // pad / idle entries hold zeros
+    const float mean = bsum<NT>(s1, red) / n;
+    float s2 = 0.f;
+    {
+        int row = tid / Tp, e = tid - row * Tp;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            if (row < R && e >= 1 && e <= T) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
+            }
+            row += dq; e += dr;
+            if (e >= Tp) { e -= Tp; ++row; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(bsum<NT>(s2, red) / n + eps);
+    if (tid < R * 4) {
+        const float aa = rstd * ga * sc;
+        cA[tid] = aa;
+        cB[tid] = be * sc + sh;
+    }
+    __syncthreads();
+    float* yb = y + ((long long)b * nq + (long long)g * bpg) * 2 * Tp * 4;      // the group's rows are contiguous in the output
+    {
+        int row = tid / Tp, e = tid - row * Tp, idx = tid;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            if (row < R) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};                              // pad frames written as zeros
+                if (e >= 1 && e <= T) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(cA + row * 4), b4 = *reinterpret_cast<const f32x4*>(cB + row * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float r = (v[i][j] - mean) * a4[j] + b4[j];
+                        if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
+                        o[j] = r;
+                    }
+                }
+                *reinterpret_cast<f32x4*>(yb + (long long)idx * 4) = o;
+            }
+            row += dq; e += dr; idx += NT;
+            if (e >= Tp) { e -= Tp; ++row; }
+        }
+    }
+}
+
+template <int MAXI>
+static hipError_t launch_gn_fused(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                                  const float* beta, const float* ss, int ss_stride, int ss_off, int silu, float* y, int B, hipStream_t s) {
+    hipLaunchKernelGGL(gn_fused_kernel<MAXI>, dim3(groups, B), dim3(1024), 0, s, x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss,
+                       ss_stride, ss_off, silu, y);
+    return hipGetLastError();
+}
+
 hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                            const float* beta, const float* ss, int ss_stride, int ss_off, int silu, float4* part, float* y, int B,
                            hipStream_t s) {
     const int C = C1 + C2;
     if ((C1 & 7) || (C2 & 7) || (C / 8) % groups) return hipErrorInvalidValue;
+    static const bool two_kernels = getenv("LDS_GN_SPLIT") != nullptr;      // experiments only
+    const long long entries = (long long)(C / 8 / groups) * 2 * (T + 2);
+    const int need = (int)((entries + 1023) / 1024);
+    if (!two_kernels && need <= 12 && 2 * (C / 8 / groups) <= 64) {          // the group fits one workgroup's registers
+        ProfScope ps(s, "gn_fused", 0.0, 4.0 * 2.0 * B * (double)C * T);
+        if (need <= 2) return launch_gn_fused<2>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
+        if (need <= 4) return launch_gn_fused<4>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
+        if (need <= 9) return launch_gn_fused<9>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
+        return launch_gn_fused<12>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
+    }
     {
         ProfScope ps(s, "gn_part", 0.0, 4.0 * 2.0 * B * (double)C * T);
         hipLaunchKernelGGL(gn_part_kernel, dim3(C / 8, B), dim3(256), 0, s, x1, x2 ? x2 : x1, C1, C2, T, part);

@@ -134,7 +134,10 @@ def test_conv_dma_layernorm_partials():
 
 
 @pytest.mark.parametrize("C1,C2,T,silu,ss", [(64, 0, 64, 1, False), (80, 176, 50, 1, False), (128, 0, 64, 1, True), (256, 0, 37, 0, False),
-                                             (512, 384, 128, 1, False)])
+                                             (512, 384, 128, 1, False),
+                                             (256, 256, 512, 1, True),      # 9 register entries per thread (largest model shape)
+                                             (512, 0, 700, 1, False),       # 12 entries per thread
+                                             (64, 64, 3000, 1, True)])      # group too large for one workgroup: gn_part + gn_apply
 def test_gn_apply(C1, C2, T, silu, ss):
     from lds import native
     from oracle import unet1d
