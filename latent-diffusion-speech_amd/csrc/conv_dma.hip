@@ -16,8 +16,10 @@
 //     (instead of once per output-channel block inside the GEMM);
 //   * the k3 taps are shifted reads of the same LDS window; skip-concat = second source pointer selected per
 //     K-step; nearest-2x upsample = (frame >> 1) in the operand address; stride 2 = operand stride.
-// Pipeline: NST-stage LDS ring, every wave issues 1/4 of each tile's DMA NST-1 tiles ahead, waits with a COUNTED
-// vmcnt for its share of the current tile, then one s_barrier per K-step (no vmcnt(0) drain).
+// Pipeline: NST-stage LDS ring; every wave issues 1/4 of each tile's DMA.  The operand registers form a ring that is
+// read NB-1 MFMA groups ahead and runs THROUGH the K-step boundary: the per-tile synchronisation (counted vmcnt for
+// this wave's share of the next tile, one s_barrier, refill of the stage just finished) sits NB-1 groups before the
+// end of a K-step, where the ring starts reading the next tile, so no K-step begins with an exposed LDS latency.
 #include "k4p.h"
 #include "kernels.h"
 
@@ -42,7 +44,7 @@ struct DmaCfg {
     static constexpr int NXI = (RPW * XW + 63) / 64;                    // activation DMA wave-instructions per wave
     static constexpr int PER_TILE = WPW + NXI;                          // VMEM ops per wave per tile
     static constexpr int G = KT * BK / 8;                               // MFMA groups per K-step (4 k-pairs each)
-    static constexpr int NB = (TM * TN >= 4) ? 2 : 3;                   // operand ring depth
+    static constexpr int NB = (G % 3 == 0 && TM * TN < 4) ? 3 : 2;      // operand ring depth (divides G: slots keep their phase across K-steps)
     static constexpr int NACC = (TM * TN >= 2) ? 1 : 2;                 // independent accumulator chains per tile
     static constexpr int STAGE = KT * BK * BM + KR * XW * 4;            // floats
     static constexpr size_t LDS_BYTES = (size_t)NST * STAGE * sizeof(float);
@@ -61,8 +63,9 @@ struct DmaKernel {
     const DmaConvArgs& p;
     float* smem;
     int lane, wave, c, h, wm, wn, b, m0, t0;
-    int woff[WPW];            // per-lane float offsets of this wave's weight chunks (loop invariant)
-    int xoff[NXI];            // per-lane float offsets of this wave's activation chunks inside a source slab
+    int woff[WPW];            // per-lane byte offsets of this wave's weight chunks (loop invariant)
+    int xoff[NXI];            // per-lane byte offsets of this wave's activation chunks inside a source slab
+    __amdgpu_buffer_rsrc_t rw, rx1, rx2;   // packed weights; this batch element's slab of either source
     bool xact[NXI];
     int arow;
     int bcol[TN];
@@ -98,7 +101,7 @@ struct DmaKernel {
             const int tap = q / (KR * BM);
             const int rem = q - tap * (KR * BM);
             const int rr = rem / BM, m = rem - rr * BM;
-            woff[i] = ((tap * (p.Ci / 4) + rr) * p.Mp + m0 + m) * 4;
+            woff[i] = ((tap * (p.Ci / 4) + rr) * p.Mp + m0 + m) * 16;
         }
         const int Tp = p.Tsrc + 2;
         const int e0 = UPS ? (((t0 - 1) >> 1) + 1) : (t0 * STRIDE - p.pad + 1);   // first window entry (pad frame = entry 0)
@@ -107,8 +110,11 @@ struct DmaKernel {
             const int qq = i * 64 + lane;
             const int rl = qq / XW, col = qq - rl * XW;
             xact[i] = qq < RPW * XW;
-            xoff[i] = ((wave * RPW + rl) * Tp + e0 + col) * 4;
+            xoff[i] = ((wave * RPW + rl) * Tp + e0 + col) * 16;
         }
+        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, KT * p.Ci * p.Mp * 4, 0x00020000);
+        rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1 + (long long)b * p.C1 * Tp), 0, p.C1 * Tp * 4, 0x00020000);
+        rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 + (long long)b * p.C2 * Tp : p.x1), 0, p.C2 * Tp * 4, 0x00020000);
         arow = wm * TM * 32 + c;
 #pragma unroll
         for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
@@ -122,23 +128,24 @@ struct DmaKernel {
                     for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
     }
 
-    // tile kc -> LDS stage `st`: this wave's share of the weight chunks and of the activation window
+    // tile kc -> LDS stage `st`: this wave's share of the weight chunks and of the activation window.  Buffer-addressed
+    // LDS-DMA: per-lane byte offsets are loop invariant (VGPR), the K-step advance is a scalar offset, so issuing a tile
+    // costs no vector ALU work; reads past a source slab return zeros (hardware range check).
     __device__ __forceinline__ void issue_tile(int kc, float* st) {
-        const float* wb = p.w + (long long)kc * KR * p.Mp * 4;
+        const int ws = kc * (KR * 16) * p.Mp;                    // bytes
 #pragma unroll
         for (int i = 0; i < WPW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + woff[i]),
-                                             (__attribute__((address_space(3))) void*)(st + ((wave + 4 * i) * 64) * 4), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + ((wave + 4 * i) * 64) * 4), 16, woff[i], ws, 0, 0);
         const int k0 = kc * BK;
         const bool s2 = k0 >= p.C1;                              // C1 % BK == 0: a K-step reads one source only
-        const int Tp = p.Tsrc + 2;
-        const float* xb = s2 ? (p.x2 + ((long long)b * p.C2 + (k0 - p.C1)) * Tp) : (p.x1 + ((long long)b * p.C1 + k0) * Tp);
+        const int xsoff = (s2 ? k0 - p.C1 : k0) * (p.Tsrc + 2) * 4;
         float* xs = st + KT * BK * BM + wave * RPW * XW * 4;
 #pragma unroll
         for (int i = 0; i < NXI; ++i)
-            if (xact[i])
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
-                                                 (__attribute__((address_space(3))) void*)(xs + i * 64 * 4), 16, 0, 0);
+            if (xact[i]) {
+                if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (__attribute__((address_space(3))) void*)(xs + i * 64 * 4), 16, xoff[i], xsoff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (__attribute__((address_space(3))) void*)(xs + i * 64 * 4), 16, xoff[i], xsoff, 0, 0);
+            }
     }
 
     template <int SLOT>
@@ -170,14 +177,32 @@ struct DmaKernel {
             preload<g0 + 1, g1>(cur);
         }
     }
+    // Tile boundary, reached when the operand ring is about to read its first group of tile kc+1: this wave has issued
+    // (and, after the lgkmcnt wait, completed) all its reads of tile kc.  After the barrier tile kc+1 is visible to
+    // everyone and tile kc's stage is free, so it is refilled with tile kc+NST.
+    __device__ __forceinline__ void tile_sync(int kc, int nk, float* cur) {
+        const int younger = (nk - 2 - kc < NST - 2) ? (nk - 2 - kc) : (NST - 2);     // tiles after kc+1 still in flight
+        wait_younger<NST - 2>(younger);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kc + NST < nk && !(p.dbg & 1)) issue_tile(kc + NST, cur);
+    }
     template <int g>
-    __device__ __forceinline__ void kstep(const float* cur) {
+    __device__ __forceinline__ void kstep(float* cur, const float* nxt, int kc, int nk) {
         if constexpr (g < G) {
-            if constexpr (g == 0) preload<0, NB - 1>(cur);
-            if constexpr (g + NB - 1 < G) load_ops<(g + NB - 1) % NB>(cur, (g + NB - 1) / (BK / 8), (g + NB - 1) % (BK / 8));
+            constexpr int gp = g + NB - 1;                     // group whose operands are fetched now
+            if constexpr (gp < G) {
+                load_ops<gp % NB>(cur, gp / (BK / 8), gp % (BK / 8));
+            } else {
+                if (kc + 1 < nk) {
+                    if constexpr (gp == G) tile_sync(kc, nk, cur);
+                    load_ops<gp % NB>(nxt, (gp - G) / (BK / 8), (gp - G) % (BK / 8));
+                }
+            }
             mfma_ops<g % NB>();
             __builtin_amdgcn_sched_barrier(0);     // keep the operand reads NB-1 groups ahead of their MFMAs
-            kstep<g + 1>(cur);
+            kstep<g + 1>(cur, nxt, kc, nk);
         }
     }
 
@@ -212,25 +237,32 @@ struct DmaKernel {
         }
     }
 
+    // s_waitcnt vmcnt(y * PER_TILE) for a wave-uniform y in [0, Y]: the y younger tiles' DMAs may stay in flight
+    template <int Y>
+    __device__ __forceinline__ void wait_younger(int y) {
+        if constexpr (Y == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            constexpr int N = (Y * PER_TILE > 63) ? 63 : Y * PER_TILE;      // vmcnt is a 6-bit field; a smaller count only waits longer
+            if (y >= Y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+            else wait_younger<Y - 1>(y);
+        }
+    }
+
     __device__ __forceinline__ void mainloop() {
-        constexpr int AHEAD = NST - 1;
+        static_assert(G % NB == 0 && NB - 1 <= G, "ring slots must keep their phase across K-steps");
         const int nk = p.Ci / BK;
-        for (int t = 0; t < AHEAD && t < nk; ++t) issue_tile(t, smem + t * STAGE);
+        for (int t = 0; t < NST && t < nk; ++t) issue_tile(t, smem + t * STAGE);
         if (p.ln_part) ln_columns();
-        int sc = 0, sn = AHEAD % NST;
+        wait_younger<NST - 1>((nk - 1 < NST - 1) ? nk - 1 : NST - 1);      // tile 0 landed (this wave's share)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        preload<0, NB - 1>(smem);
+        int sc = 0;
         for (int kc = 0; kc < nk; ++kc) {
-            // this wave's share of tile kc has landed when at most the younger tiles' DMAs are outstanding
-            const int younger = (nk - 1 - kc < AHEAD - 1) ? (nk - 1 - kc) : (AHEAD - 1);
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // every wave's share landed; every wave is done with the stage refilled below
-            asm volatile("" ::: "memory");
-            if (kc + AHEAD < nk) issue_tile(kc + AHEAD, smem + sn * STAGE);
-            kstep<0>(smem + sc * STAGE);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            sc = (sc + 1 == NST) ? 0 : sc + 1;
-            sn = (sn + 1 == NST) ? 0 : sn + 1;
+            const int sn = (sc + 1 == NST) ? 0 : sc + 1;
+            kstep<0>(smem + sc * STAGE, smem + sn * STAGE, kc, nk);
+            sc = sn;
         }
     }
 
@@ -414,7 +446,10 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
 #define DCASE(BM, BN, KT, ST, UP, BK, NS) return launch_dma_cfg<BM, BN, KT, ST, UP, BK, NS>(a, s)
 
 // cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
-hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
+hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
+    DmaConvArgs a = a_in;
+    static const int env_dbg = getenv("LDS_DMA_DBG") ? atoi(getenv("LDS_DMA_DBG")) : 0;      // experiments only
+    a.dbg = env_dbg;
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || (a.pad != 0 && a.pad != 1)) return hipErrorInvalidValue;
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     static const int env_cfg = getenv("LDS_DMA_CFG") ? atoi(getenv("LDS_DMA_CFG")) : 0;     // experiments only
@@ -475,16 +510,24 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
             if (bk == 32 && nst == 3) DCASE(64, 64, 1, 1, false, 32, 3);
             if (bk == 16 && nst == 2) DCASE(64, 64, 1, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(64, 64, 1, 1, false, 16, 3);
+            if (bk == 64 && nst == 4) DCASE(64, 64, 1, 1, false, 64, 4);
+            if (bk == 32 && nst == 4) DCASE(64, 64, 1, 1, false, 32, 4);
+            if (bk == 32 && nst == 5) DCASE(64, 64, 1, 1, false, 32, 5);
+            if (bk == 16 && nst == 4) DCASE(64, 64, 1, 1, false, 16, 4);
+            if (bk == 16 && nst == 6) DCASE(64, 64, 1, 1, false, 16, 6);
         } else if (tk == 128064) {
             if (bk == 32 && nst == 2) DCASE(128, 64, 1, 1, false, 32, 2);
             if (bk == 32 && nst == 3) DCASE(128, 64, 1, 1, false, 32, 3);
             if (bk == 16 && nst == 2) DCASE(128, 64, 1, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(128, 64, 1, 1, false, 16, 3);
+            if (bk == 32 && nst == 4) DCASE(128, 64, 1, 1, false, 32, 4);
+            if (bk == 16 && nst == 4) DCASE(128, 64, 1, 1, false, 16, 4);
         } else if (tk == 128128) {
             if (bk == 32 && nst == 2) DCASE(128, 128, 1, 1, false, 32, 2);
             if (bk == 32 && nst == 3) DCASE(128, 128, 1, 1, false, 32, 3);
             if (bk == 16 && nst == 2) DCASE(128, 128, 1, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(128, 128, 1, 1, false, 16, 3);
+            if (bk == 16 && nst == 4) DCASE(128, 128, 1, 1, false, 16, 4);
         }
     } else if (key == 310) {
         if (tk == 64064) {
@@ -492,6 +535,8 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
             if (bk == 32 && nst == 3) DCASE(64, 64, 3, 1, false, 32, 3);
             if (bk == 16 && nst == 2) DCASE(64, 64, 3, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(64, 64, 3, 1, false, 16, 3);
+            if (bk == 16 && nst == 4) DCASE(64, 64, 3, 1, false, 16, 4);
+            if (bk == 32 && nst == 4) DCASE(64, 64, 3, 1, false, 32, 4);
         } else if (tk == 128064) {
             if (bk == 16 && nst == 2) DCASE(128, 64, 3, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(128, 64, 3, 1, false, 16, 3);

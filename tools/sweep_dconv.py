@@ -34,16 +34,22 @@ def run(L, B, Ci, Co, T, K, cfg, res, iters=30):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfgs", default="64064642,64064323")
+    ap.add_argument("--Bs", default="4,8,16,32,64")
+    ap.add_argument("--Co", type=int, default=256)
+    ap.add_argument("--K", type=int, default=1)
+    args = ap.parse_args()
     L = native.lib()
-    for cfg in (64064642, 64064323):
+    cis = (64, 128, 256, 512, 1024, 2048)
+    for cfg in [int(c) for c in args.cfgs.split(",")]:
         print("cfg", cfg)
-        for B in (4, 8, 16, 32, 64):
-            row = []
-            for Ci in (64, 128, 256, 512, 1024, 2048):
-                us, _ = run(L, B, Ci, 256, 512, 1, cfg, False)
-                row.append(us)
-            wgs = B * 512 // 64 * 4
-            print(f"  B={B:3d} WGs={wgs:5d}  " + "  ".join(f"Ci{c}:{u:6.1f}us" for c, u in zip((64, 128, 256, 512, 1024, 2048), row)), flush=True)
+        for B in [int(b) for b in args.Bs.split(",")]:
+            row = [run(L, B, Ci, args.Co, 512, args.K, cfg, False)[0] for Ci in cis]
+            fl = 2.0 * B * 512 * args.Co * args.K * (cis[-1] - cis[-2])
+            slope_tf = fl / ((row[-1] - row[-2]) * 1e-6) / 1e12
+            print(f"  B={B:3d}  " + "  ".join(f"Ci{c}:{u:6.1f}us" for c, u in zip(cis, row)) + f"   main-loop slope {slope_tf:6.1f} TF", flush=True)
 
 
 if __name__ == "__main__":
