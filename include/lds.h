@@ -183,7 +183,6 @@ int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, in
 /* mid = w1*x (1x1, [C,C]); out = w2 * LayerNorm_C(mid) (1x1, [Co,C]); statistics travel as epilogue partials */
 int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
                       float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
-int lds_test_attention(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
 int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
                             float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
                             float in_slope, void* stream);

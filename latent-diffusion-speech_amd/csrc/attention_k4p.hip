@@ -1,11 +1,15 @@
 // Self-attention for the K4P UNet path (reference Attention + AttnProcessor2_0, attention_processor.py:980-1052).
-// Same algorithm as attention.hip (swapped QK^T so each lane owns one query column, probabilities fed from the
-// accumulator registers straight into the P.V MFMAs), but all operands are vector LDS reads:
-//   q, k arrive in K4P (k4p.h): the 4 floats at one (row, frame) are the head-dim values 8q+2j+h, j=0..3, i.e.
-//   the A (keys) / B (queries) operands of four consecutive v_mfma_f32_32x32x2_f32 -> one ds_read_b128 per 4 MFMAs;
-//   v arrives frame-major [d][frames] (the QKV conv stores that third plain), staged with pitch 68 so that one
-//   conflict-free ds_read_b128 = V[d][4 consecutive keys] = the A operands of the four P.V MFMAs that consume
-//   accumulator registers 4g..4g+3.
+// Flash-style, fp32 MFMA (v_mfma_f32_32x32x2_f32), swapped QK^T so each lane owns one query column and the
+// probabilities go from the accumulator registers straight into the P.V MFMAs.  Built like conv_dma: key/value tiles
+// travel L2 -> LDS by buffer-addressed LDS-DMA (no staging registers, no vector address math), in an NST-stage ring
+// with counted vmcnt waits and one s_barrier per 64-key tile; every operand is one ds_read_b128 per four MFMAs.
+//   q, k arrive in K4P (k4p.h): the 4 floats at one (row, frame) are the head-dim values 8q+2j+h, j=0..3, i.e. the
+//   A (keys) / B (queries) operands of four consecutive MFMAs; a 64-key tile of one row is 1 KB contiguous.
+//   v arrives in the "VT" layout the QKV convolution writes for it: [B][heads][ceil(T/4)][D][4], the 4 floats being
+//   V[d] at 4 consecutive keys = the A operands of the four P.V MFMAs that consume accumulator registers 4g..4g+3; a
+//   64-key tile of one head is D*256 contiguous bytes and a wave's read (d = lane) is conflict-free.
+// Keys >= T: their scores are masked to -inf in the last tile; their K entries are pad zeros / neighbouring rows
+// (finite) and their V entries are zeros (VT tail written by the producer, or the buffer range check), so 0 * V = 0.
 // Output is written in K4P (two 8-byte stores per 8-channel block, pad frames included).
 #include "k4p.h"
 #include "kernels.h"
@@ -18,18 +22,51 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int D, int NW>
-__global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vp, float* __restrict__ out,
+template <int D, int NW, int NST>
+struct AttCfg {
+    static constexpr int KB = 64;                       // keys per tile
+    static constexpr int DQ = D / 8, DT = (D + 31) / 32;
+    static constexpr int KROWS = DQ * 2;                // K4P rows of one head = 1 KB DMA instructions per K tile
+    static constexpr int VCH = D / 4;                   // 1 KB DMA instructions per V tile (16 key-quads x D x 16 B)
+    static constexpr int KPW = KROWS / NW, VPW = VCH / NW;
+    static constexpr int PER_TILE = KPW + VPW;          // VMEM ops per wave per tile
+    static constexpr int STAGE = 2 * KB * D;            // floats: K tile + V tile
+    // + slack: with D = 48 the second 32-row operand tile reads up to 15 entries past the last V tile (rows never stored)
+    static constexpr size_t LDS_BYTES = (size_t)NST * STAGE * sizeof(float) + 256;
+    static_assert(KROWS % NW == 0 && VCH % NW == 0, "tile must split evenly over the waves");
+};
+
+template <int Y, int PER_TILE>
+static __device__ __forceinline__ void att_wait_younger(int y) {
+    if constexpr (Y == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        constexpr int N = (Y * PER_TILE > 63) ? 63 : Y * PER_TILE;      // vmcnt is a 6-bit field; a smaller count only waits longer
+        if (y >= Y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        else att_wait_younger<Y - 1, PER_TILE>(y);
+    }
+}
+
+// tile kt -> LDS stage `st`: this wave's share of the K rows and of the V chunks (1 KB per instruction)
+template <int D, int NW, int KPW, int VPW>
+static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc_t rk, const __amdgpu_buffer_rsrc_t rv, const int (&koff)[KPW],
+                                                      const int (&voff)[VPW], int wave, int kt, float* st) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 256), 16, koff[i], kt * (64 * 16), 0, 0);
+#pragma unroll
+    for (int i = 0; i < VPW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + 64 * D + (wave + NW * i) * 256), 16, voff[i],
+                                                 kt * (64 * D * 4), 0, 0);
+}
+
+template <int D, int NW, int NST>
+__global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ out,
                                                                 int C, int T, float scale2) {
-    constexpr int DQ = D / 8;              // 8-channel blocks per head
-    constexpr int DT = (D + 31) / 32;
-    constexpr int KB = 64, VP = 68;
-    constexpr int KSZ = DQ * 2 * KB * 4, VSZ = DT * 32 * VP;
-    constexpr int NKL = DQ * 2 * KB / (NW * 64), NVL = D * (KB / 4) / (NW * 64);   // 16-byte entries per thread and tile
-    static_assert(NKL * NW * 64 == DQ * 2 * KB && NVL * NW * 64 == D * (KB / 4), "tile must split evenly over the threads");
-    __shared__ __attribute__((aligned(16))) float Ks[2 * KSZ];   // two stages of [kq][h][key][4]
-    __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ];   // two stages of [d][key], pitch 68
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    using Cfg = AttCfg<D, NW, NST>;
+    constexpr int KB = Cfg::KB, DQ = Cfg::DQ, DT = Cfg::DT, KPW = Cfg::KPW, VPW = Cfg::VPW, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // NST x { K [row][key][4] ; V [keyquad][d][4] }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 31, h = lane >> 5;
     // XCD-aware order: the query blocks of one (batch, head) share K and V, so they take consecutive slots of one XCD
     // (workgroups are dispatched round-robin over the 8 XCDs, each with its own L2)
@@ -39,18 +76,31 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     const int L = xcd * per + (xcd < rem ? xcd : rem) + (id >> 3);
     const int qblk = L % gx, hd = (L / gx) % gy, b = L / (gx * gy);
     const int tq = qblk * (NW * 32) + wave * 32 + c;
-    const int Tp = T + 2;
+    const int Tp = T + 2, T4 = (T + 3) & ~3;
     const float* qb = qk + ((long long)b * 2 * C + (long long)hd * D) * Tp;            // q rows of this head
-    const float* kb = qk + ((long long)b * 2 * C + C + (long long)hd * D) * Tp;        // k rows
-    const float* vb = vp + ((long long)b * C + (long long)hd * D) * T;
 
+    // queries: B operands, pre-multiplied by log2(e)/sqrt(d) so the scores come out in log2 units
     f32x4 qv[DQ];
 #pragma unroll
     for (int kq = 0; kq < DQ; ++kq) {
         qv[kq] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (tq < T) qv[kq] = *reinterpret_cast<const f32x4*>(qb + ((long long)(kq * 2 + h) * Tp + tq + 1) * 4);
     }
-    for (int i = tid; i < (DT * 32 - D) * VP; i += NW * 64) Vs[D * VP + i] = Vs[VSZ + D * VP + i] = 0.f;   // head-dim padding rows (D = 48)
+
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qk + ((long long)b * 2 * C + C + (long long)hd * D) * Tp), 0, D * Tp * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vt + ((long long)b * C + (long long)hd * D) * T4), 0, D * T4 * 4, 0x00020000);
+    // loop-invariant per-lane byte offsets of this wave's DMA shares
+    int koff[KPW], voff[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) koff[i] = (((wave + NW * i) * Tp) + lane + 1) * 16;
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) voff[i] = ((wave + NW * i) * 64 + lane) * 16;
+    const int nt = (T + KB - 1) / KB;
+    for (int t = 0; t < NST - 1 && t < nt; ++t) att_issue_tile<D, NW>(rk, rv, koff, voff, wave, t, smem + t * STAGE);
+#pragma unroll
+    for (int kq = 0; kq < DQ; ++kq) qv[kq] *= scale2;
 
     f32x16 o[DT];
 #pragma unroll
@@ -58,80 +108,46 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const bool vec = (T & 3) == 0;
 
-    // software pipeline: the next key tile travels global -> registers while the current one is consumed from LDS
-    f32x4 kreg[NKL], vreg[NVL];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < NKL; ++i) {                                   // K: straight 16-byte copies of K4P entries
-            const int idx = tid + i * NW * 64, row = idx / KB, key = idx - row * KB;
-            kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (k0 + key < T) kreg[i] = *reinterpret_cast<const f32x4*>(kb + ((long long)row * Tp + k0 + key + 1) * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < NVL; ++i) {                                   // V: rows of 64 keys
-            const int idx = tid + i * NW * 64, d = idx / (KB / 4), j = (idx - d * (KB / 4)) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (vec && k0 + j + 3 < T) {
-                v = *reinterpret_cast<const f32x4*>(vb + (long long)d * T + k0 + j);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (k0 + j + e < T) ? vb[(long long)d * T + k0 + j + e] : 0.f;
-            }
-            vreg[i] = v;
-        }
-    };
-    auto stash = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < NKL; ++i) {
-            const int idx = tid + i * NW * 64;
-            *reinterpret_cast<f32x4*>(Ks + stage * KSZ + idx * 4) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NVL; ++i) {
-            const int idx = tid + i * NW * 64, d = idx / (KB / 4), j = (idx - d * (KB / 4)) * 4;
-            *reinterpret_cast<f32x4*>(Vs + stage * VSZ + d * VP + j) = vreg[i];
-        }
-    };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-
-    int stage = 0;
-    for (int k0 = 0; k0 < T; k0 += KB, stage ^= 1) {
-        const bool more = k0 + KB < T;
-        if (more) fetch(k0 + KB);
-        const float* Kc = Ks + stage * KSZ;
-        const float* Vc = Vs + stage * VSZ;
+    int sc = 0, sn = NST - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+        // this wave's share of tile kt has landed when at most the younger tiles' DMAs are outstanding
+        const int younger = (nt - 1 - kt < NST - 2) ? (nt - 1 - kt) : (NST - 2);
+        att_wait_younger<NST - 2, PER_TILE>(younger);
+        __builtin_amdgcn_s_barrier();              // every wave's share landed; every wave is done with the stage refilled below
+        asm volatile("" ::: "memory");
+        if (kt + NST - 1 < nt) att_issue_tile<D, NW>(rk, rv, koff, voff, wave, kt + NST - 1, smem + sn * STAGE);
+        const float* Kc = smem + sc * STAGE;
+        const float* Vc = Kc + KB * D;
 #pragma unroll 1
-        for (int kt = 0; kt < KB / 32; ++kt) {
-            const int kbase = k0 + kt * 32;
+        for (int half = 0; half < KB / 32; ++half) {
+            const int kbase = kt * KB + half * 32;
             if (kbase >= T) break;
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int kq = 0; kq < DQ; ++kq) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(Kc + ((kq * 2 + h) * KB + kt * 32 + c) * 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(Kc + ((kq * 2 + h) * KB + half * 32 + c) * 4);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], qv[kq][jj], s, 0, 0, 0);
             }
-            // scores are kept in log2 units (scale2 = log2(e)/sqrt(d)) so every exponential is one v_exp_f32; all of this
-            // VALU work is paid in matrix time on gfx950 (the fp32 MFMA shares the vector ALU), so it is kept minimal
-            float mt = -INFINITY;
+            // all of this VALU work is paid in matrix time on gfx950 (the fp32 MFMA shares the vector ALU): one v_exp_f32
+            // per score, the key mask only in the ragged last tile, the rescale only when some running maximum moved
+            if (kbase + 32 > T) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                s[r] = (key < T) ? s[r] * scale2 : -INFINITY;
-                mt = fmaxf(mt, s[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * h >= T) s[r] = -INFINITY;
             }
+            float mt = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+            for (int r = 4; r < 16; r += 2) mt = fmaxf(mt, fmaxf(s[r], s[r + 1]));
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt);
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
-            if (__any(m_new != m_run)) {             // wave-uniform: rescale only when some query's running maximum moved
+            if (__any(m_new != m_run)) {             // wave-uniform
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;
 #pragma unroll
@@ -145,17 +161,20 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(Vc + (i * 32 + c) * VP + kt * 32 + 8 * g + 4 * h);
+                    // V[d = i*32 + c][keys 8g+4h .. +3]; rows d >= D (second tile of D = 48) read a neighbour's entries and
+                    // only feed output rows that are never stored
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(Vc + ((half * 8 + 2 * g + h) * D + i * 32 + c) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], s[4 * g + e], o[i], 0, 0, 0);
                 }
             }
         }
-        if (more) stash(stage ^ 1);       // that stage was last read one iteration ago, before the barrier below
-        __syncthreads();
+        sc = (sc + 1 == NST) ? 0 : sc + 1;
+        sn = (sn + 1 == NST) ? 0 : sn + 1;
     }
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     if (tq < T) {
+        const float rl = 1.0f / l;
         float* ob = out + (long long)b * C * Tp;
 #pragma unroll
         for (int i = 0; i < DT; ++i)
@@ -166,7 +185,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const long long off = ((long long)(q * 2 + hh) * Tp + tq + 1) * 4 + 2 * h;
-                    *reinterpret_cast<f32x2*>(ob + off) = f32x2{o[i][4 * g + hh] / l, o[i][4 * g + 2 + hh] / l};
+                    *reinterpret_cast<f32x2*>(ob + off) = f32x2{o[i][4 * g + hh] * rl, o[i][4 * g + 2 + hh] * rl};
                     if (tq == 0) *reinterpret_cast<f32x2*>(ob + off - 4) = f32x2{0.f, 0.f};
                     if (tq == T - 1) *reinterpret_cast<f32x2*>(ob + off + 4) = f32x2{0.f, 0.f};
                 }
@@ -174,21 +193,37 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     }
 }
 
-template <int D>
-static hipError_t launch_dk(const float* qk, const float* v, float* out, int B, int C, int T, int heads, hipStream_t s) {
-    const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
-    if (T > 64) hipLaunchKernelGGL((attention_k4p_kernel<D, 4>), dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qk, v, out, C, T, scale);
-    else hipLaunchKernelGGL((attention_k4p_kernel<D, 2>), dim3((T + 63) / 64, heads, B), dim3(128), 0, s, qk, v, out, C, T, scale);
+template <int D, int NW, int NST>
+static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, hipStream_t s) {
+    using Cfg = AttCfg<D, NW, NST>;
+    auto kern = attention_k4p_kernel<D, NW, NST>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((T + NW * 32 - 1) / (NW * 32), heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);
     return hipGetLastError();
 }
 
-hipError_t launch_attention_k4p(const float* qk, const float* v, float* out, int B, int C, int T, int heads, hipStream_t s) {
+template <int D>
+static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
+    const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
+    // queries per workgroup: 128 (four waves share each K/V tile) when that still gives every CU a workgroup, else 64
+    // (32 for a single tile)
+    if ((long long)((T + 127) / 128) * heads * B >= 256) return launch_cfg<D, 4, (D == 64 ? 2 : 3)>(qk, vt, out, B, C, T, heads, scale, s);
+    if (T > 32) return launch_cfg<D, 2, (D == 64 ? 2 : 3)>(qk, vt, out, B, C, T, heads, scale, s);
+    return launch_cfg<D, 1, 2>(qk, vt, out, B, C, T, heads, scale, s);
+}
+
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
     if (C % heads) return hipErrorInvalidValue;
     ProfScope ps(s, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T);
     switch (C / heads) {
-        case 32: return launch_dk<32>(qk, v, out, B, C, T, heads, s);
-        case 48: return launch_dk<48>(qk, v, out, B, C, T, heads, s);
-        case 64: return launch_dk<64>(qk, v, out, B, C, T, heads, s);
+        case 32: return launch_dk<32>(qk, vt, out, B, C, T, heads, s);
+        case 48: return launch_dk<48>(qk, vt, out, B, C, T, heads, s);
+        case 64: return launch_dk<64>(qk, vt, out, B, C, T, heads, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -319,6 +319,23 @@ struct DmaKernel {
         }
     }
 
+    // attention's VT layout for the value channels (attention_k4p.hip): [B][head][ceil(To/4)][D][4], element = V[d] at 4
+    // consecutive frames; frames To .. ceil4(To)-1 are written as zeros (they are multiplied by zero probabilities)
+    __device__ __forceinline__ void store_vt(int c0, int i, int j, int n) {
+        const int T4 = (p.To + 3) & ~3, D = p.vt_D, Cv = p.Cout - p.plain_from;
+        if (n >= T4) return;
+        const bool real = n < p.To;
+        const int head0 = c0 / D, rem0 = c0 - head0 * D;
+        float* ob = p.out2 + (long long)b * Cv * T4 + (long long)(n >> 2) * D * 4 + (n & 3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            int d = rem0 + rl, head = head0;
+            if (d >= D) { d -= D; ++head; }
+            if (c0 + rl < Cv) ob[(long long)head * D * T4 + d * 4] = real ? acc[0][i][j][r] : 0.f;
+        }
+    }
+
     // K4P addressing of one 32x32 tile.  Registers (4g+hh, 4g+2+hh) of this lane are elements (2h, 2h+1) of row
     // (q = tile0/8 + g, hh): two 8-byte accesses per 8-channel block; the two lane halves together fill the 16-byte entry,
     // and consecutive lanes are consecutive frames.
@@ -406,7 +423,10 @@ struct DmaKernel {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
                 const int tile0 = tile_ch(i, geglu);
                 if (p.out_plain) store_plain(p.out, p.Cout, tile0, i, j, n);
-                else if (tile0 >= p.plain_from) store_plain(p.out2, p.Cout - p.plain_from, tile0 - p.plain_from, i, j, n);
+                else if (tile0 >= p.plain_from) {
+                    if (p.vt_D) store_vt(tile0 - p.plain_from, i, j, n);
+                    else store_plain(p.out2, p.Cout - p.plain_from, tile0 - p.plain_from, i, j, n);
+                }
                 else if (tile0 < p.Cout) store_k4p(tile0, i, j, n);
             }
         }

@@ -72,6 +72,19 @@ hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hip
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) plain_to_vt_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int D) {
+    const int ch = blockIdx.x, b = blockIdx.y;
+    const int T4 = (T + 3) & ~3, head = ch / D, d = ch - head * D;
+    const float* ib = in + ((long long)b * C + ch) * T;
+    float* ob = out + ((long long)b * C + (long long)head * D) * T4 + d * 4;
+    for (int n = threadIdx.x; n < T4; n += 256) ob[(long long)(n >> 2) * D * 4 + (n & 3)] = (n < T) ? ib[n] : 0.f;
+}
+hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, int D, hipStream_t s) {
+    if (D <= 0 || C % D) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(plain_to_vt_kernel, dim3(C, B), dim3(256), 0, s, in, out, C, T, D);
+    return hipGetLastError();
+}
+
 // ---- GroupNorm: pass 1, per 8-channel block (mean, M2) over its 8*T real elements.  One read: sums of (x - k) and
 //      (x - k)^2 with k = the block's first element (a shift close to the mean removes the cancellation of the naive
 //      sum / sum-of-squares form); blocks are combined in pass 2 with Chan's formula ----

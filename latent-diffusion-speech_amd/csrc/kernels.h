@@ -71,7 +71,8 @@ struct DmaConvArgs {
     int epi;                            // EPI_NONE | EPI_GEGLU
     float* out;                         // K4P [B][min(Cout, plain_from)][To], or plain [B][Cout][To] when out_plain
     int out_plain;
-    int plain_from; float* out2;        // output channels >= plain_from go frame-major to out2 [B][Cout-plain_from][To]
+    int plain_from; float* out2;        // output channels >= plain_from go frame-major to out2 [B][Cout-plain_from][To] ...
+    int vt_D;                           // ... or, when vt_D > 0, in attention's VT layout [B][(Cout-plain_from)/vt_D][ceil(To/4)][vt_D][4]
     float2* lnpart_out;                 // optional [B][C/32][To] per-frame (mean, M2) partials over 32-channel tiles
     // LayerNorm of the INPUT folded into the epilogue (weights pre-multiplied by gamma on the host):
     //   y[m,t] = rstd_t * (acc[m,t] - mean_t * ln_c1[m]) + ln_c2[m],  c1 = sum_c W[m,c]*gamma_c,  c2 = sum_c W[m,c]*beta_c + bias[m]
@@ -90,6 +91,9 @@ const char* conv_dma_last_config();
 // plain [B][C][T] -> channels [c_off, c_off+C) of a K4P tensor with Ctot channels (pads of those rows zeroed)
 hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s);
 hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hipStream_t s);
+// plain [B][C][T] -> attention's VT layout [B][C/D][ceil(T/4)][D][4] (tail keys zeroed); the UNet gets this layout straight
+// from the QKV convolution's epilogue, this kernel serves the stand-alone attention entry point
+hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, int D, hipStream_t s);
 // GroupNorm of the virtual concat [x1;x2] (K4P) -> y (K4P, C1+C2 channels):
 //   y = act(((x - mean_g) * rstd_g * gamma + beta) * (1 + scale) + shift), act = SiLU if silu
 // `part` is scratch for [B][(C1+C2)/8] float4 partial statistics.
@@ -98,8 +102,9 @@ hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int
                            int silu, float4* part, float* y, int B, hipStream_t s);
 // nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
 hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
-// self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v frame-major [B][C][T]; out K4P [B][C][T]
-hipError_t launch_attention_k4p(const float* qk, const float* v, float* out, int B, int C, int T, int heads, hipStream_t s);
+// self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v in the VT layout
+// [B][heads][ceil(T/4)][D][4] (key tail zeroed); out K4P [B][C][T]
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Normalisation statistics
@@ -111,11 +116,6 @@ hipError_t launch_gn_coef(const float* x1, const float* x2, int C1, int C2, int 
                           int ss_stride, int ss_off, float4* coef, int B, hipStream_t s);
 // LayerNorm statistics over channels: mean[b][t], rstd[b][t]
 hipError_t launch_ln_stats(const float* x, int C, int T, float eps, float* mean, float* rstd, int B, hipStream_t s);
-
-// ---------------------------------------------------------------------------------------------
-// Self-attention: qkv [B][3C][T] (q rows 0..C-1, k rows C..2C-1, v rows 2C..3C-1) -> out [B][C][T]
-// ---------------------------------------------------------------------------------------------
-hipError_t launch_attention(const float* qkv, float* out, int B, int C, int T, int heads, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small dense layers with N = batch columns (time embedding path)

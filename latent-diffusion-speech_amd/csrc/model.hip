@@ -297,6 +297,7 @@ struct DOpt {
     const float* res = nullptr;
     int epi = EPI_NONE, out_plain = 0, plain_from = -1;
     float* out2 = nullptr;
+    int vt_D = 0;
     float2* lnpart_out = nullptr;
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
@@ -312,7 +313,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     a.res = o.res; a.epi = o.epi; a.out = out; a.out_plain = o.out_plain;
     a.Cout = (o.epi == EPI_GEGLU) ? W.Co / 2 : W.Co;
     a.plain_from = (o.plain_from >= 0) ? o.plain_from : a.Cout;
-    a.out2 = o.out2; a.lnpart_out = o.lnpart_out;
+    a.out2 = o.out2; a.vt_D = o.vt_D; a.lnpart_out = o.lnpart_out;
     a.ln_part = o.ln_part; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.ln_c1 = o.ln_c1; a.ln_c2 = o.ln_c2;
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
     a.To = (Tin + 2 * o.pad - (W.K - 1) - 1) / o.stride + 1;
@@ -602,7 +603,7 @@ struct UnetWs {
     float2* lnp;
     float* xin;
     std::vector<float*> skips;
-    float *cur[2], *r, *h1, *sc, *ta, *tb, *upt, *gno, *lnb, *qk, *v, *att, *ff;
+    float *cur[2], *r, *h1, *sc, *ta, *tb, *upt, *gno, *qk, *v, *att, *ff;
     int ss_stride = 0;
 };
 
@@ -618,7 +619,7 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.xin = A.f(B * k4(u->M + u->H, T));
     std::vector<int> Ts{T};
     for (int i = 0; i < nb - 1; ++i) Ts.push_back(down_len(Ts.back()));
-    size_t maxct = 0, maxgn = k4(boc[0], T), maxatt = 0;
+    size_t maxct = 0, maxgn = k4(boc[0], T), maxatt = 0;      // k4(C, T) = C * (T + 2) also covers the VT layout's C * ceil4(T) up to C floats
     w.skips.clear();
     w.skips.push_back(A.f(B * k4(boc[0], T)));
     for (int i = 0; i < nb; ++i) {
@@ -648,7 +649,7 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.r = A.f(B * maxct); w.h1 = A.f(B * maxct); w.sc = A.f(B * maxct);
     w.ta = A.f(B * maxct); w.tb = A.f(B * maxct); w.upt = A.f(B * maxct);
     w.gno = A.f(B * maxgn);
-    w.lnb = A.f(B * maxatt); w.qk = A.f(B * maxatt * 2); w.v = A.f(B * maxatt); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
+    w.qk = A.f(B * maxatt * 2); w.v = A.f(B * (maxatt + 2048)); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
     w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2);
     A.f(16384);   // tail slack: ragged last tiles read (masked) entries past a tensor's end
 }
@@ -694,7 +695,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
         DOpt oq;
-        oq.plain_from = 2 * C; oq.out2 = w.v;                      // q, k in K4P; v frame-major for the P.V operand reads
+        oq.plain_from = 2 * C; oq.out2 = w.v; oq.vt_D = C / u->heads;      // q, k in K4P; v in attention's VT layout
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
         LDS_TRY(run_dconv(t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
         HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
@@ -1290,10 +1291,13 @@ static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, i
     float* kout = a->plain_out ? out : tmp.f((size_t)B * Ck * (To + 2));
     float* vout = nullptr;
     if (!kout) return fail(LDS_ENOMEM, "alloc");
+    const int To4 = (To + 3) & ~3;
     if (a->v_split) {
-        vout = tmp.f((size_t)B * (Cout - Ck) * To);
+        vout = tmp.f((size_t)B * (Cout - Ck) * To4);
         if (!vout) return fail(LDS_ENOMEM, "alloc");
+        HIP_TRY(hipMemsetAsync(vout, 0xff, sizeof(float) * B * (Cout - Ck) * To4, st));      // NaN fill: the zero tail must be written
         o.plain_from = Ck; o.out2 = vout;
+        if (a->v_split > 1) o.vt_D = a->v_split;      // value third in attention's VT layout with this head dim
     }
     o.lnpart_out = (float2*)lnpart;
     int r = run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st);
@@ -1312,7 +1316,11 @@ static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, i
         (void)hipEventDestroy(e1);
     }
     if (r == LDS_OK && !a->plain_out) {
-        if (a->v_split) {
+        if (a->v_split > 1) {
+            // out = [B][Ck][To] plain q;k, then the raw VT buffer [B][(Cout-Ck)/D][ceil4(To)/4][D][4]
+            HIP_TRY(launch_from_k4p(kout, out, B, Ck, To, st));
+            HIP_TRY(hipMemcpyAsync(out + (size_t)B * Ck * To, vout, sizeof(float) * B * (Cout - Ck) * To4, hipMemcpyDeviceToDevice, st));
+        } else if (a->v_split) {
             // out = [q;k] back to plain (first 2/3 of the channels) followed by the already-plain v third
             float* tmpo = tmp.f((size_t)B * Ck * To);
             if (!tmpo) return fail(LDS_ENOMEM, "alloc");
@@ -1393,15 +1401,17 @@ extern "C" int lds_test_attention_k4p(const float* qkv, float* out, int B, int C
     TmpDev tmp;
     float* qkp = tmp.f((size_t)B * 2 * C * T);       // plain [B][2C][T]
     float* vpl = tmp.f((size_t)B * C * T);
+    float* vt = tmp.f((size_t)B * C * (T + 3));
     float* kqk = tmp.f((size_t)B * 2 * C * (T + 2));
     float* ko = tmp.f((size_t)B * C * (T + 2));
-    if (!qkp || !vpl || !kqk || !ko) return fail(LDS_ENOMEM, "alloc");
+    if (!qkp || !vpl || !vt || !kqk || !ko) return fail(LDS_ENOMEM, "alloc");
     for (int b = 0; b < B; ++b) {
         HIP_TRY(hipMemcpyAsync(qkp + (size_t)b * 2 * C * T, qkv + (size_t)b * 3 * C * T, sizeof(float) * 2 * C * T, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(vpl + (size_t)b * C * T, qkv + (size_t)b * 3 * C * T + (size_t)2 * C * T, sizeof(float) * C * T, hipMemcpyDeviceToDevice, st));
     }
     HIP_TRY(launch_to_k4p(qkp, kqk, B, 2 * C, T, 2 * C, 0, st));
-    HIP_TRY(launch_attention_k4p(kqk, vpl, ko, B, C, T, heads, st));
+    HIP_TRY(launch_plain_to_vt(vpl, vt, B, C, T, C / heads, st));
+    HIP_TRY(launch_attention_k4p(kqk, vt, ko, B, C, T, heads, st));
     HIP_TRY(launch_from_k4p(ko, out, B, C, T, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
@@ -1431,11 +1441,6 @@ extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w
     int r = run_conv(W2, s2, o2, out, B, st);
     HIP_TRY(hipStreamSynchronize(st));
     return r;
-}
-
-extern "C" int lds_test_attention(const float* qkv, float* out, int B, int C, int T, int heads, void* stream) {
-    HIP_TRY(launch_attention(qkv, out, B, C, T, heads, (hipStream_t)stream));
-    return LDS_OK;
 }
 
 extern "C" int lds_test_conv_transpose(const float* x, const float* w, const float* bias, float* out, int B, int Ci, int Co, int T, int K,

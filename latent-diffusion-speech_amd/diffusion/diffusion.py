@@ -178,8 +178,31 @@ class GaussianDiffusion(nn.Module):
         self.denorm_spec = lambda x: x / acoustic_scale
 
     # ---- per-method coefficient tables (host, fp32) ----
+    # Host copies of the schedule buffers and the tables built from them are cached (a device->host read per call would
+    # synchronise the stream); anything that can change the buffers drops the cache.
     def _buf(self, name):
-        return self.__getattr__(name).detach().cpu().numpy().astype(f32)
+        host = self.__dict__.setdefault("_host_cache", {})
+        if name not in host:
+            host[name] = self.__getattr__(name).detach().cpu().numpy().astype(f32)
+        return host[name]
+
+    def _table(self, key, build):
+        tabs = self.__dict__.setdefault("_table_cache", {})
+        if key not in tabs:
+            tabs[key] = build()
+        return tabs[key]
+
+    def _drop_host_cache(self):
+        self.__dict__.pop("_host_cache", None)
+        self.__dict__.pop("_table_cache", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_host_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._drop_host_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _ddpm_table(self, t):
         rc, rm1 = self._buf("sqrt_recip_alphas_cumprod"), self._buf("sqrt_recipm1_alphas_cumprod")
@@ -219,8 +242,8 @@ class GaussianDiffusion(nn.Module):
         if noise is None:
             noise = torch.randn_like(x_start)
         ti = int(t.reshape(-1)[0]) if torch.is_tensor(t) else int(t)
-        return native.axpby(x_start.contiguous(), noise.contiguous(), float(self.sqrt_alphas_cumprod[ti]),
-                            float(self.sqrt_one_minus_alphas_cumprod[ti]))
+        return native.axpby(x_start.contiguous(), noise.contiguous(), float(self._buf("sqrt_alphas_cumprod")[ti]),
+                            float(self._buf("sqrt_one_minus_alphas_cumprod")[ti]))
 
     def forward(self, condition, gt_spec=None, infer=True, infer_speedup=10, method="dpm-solver", k_step=None, use_tqdm=False):
         if not infer:
@@ -239,23 +262,22 @@ class GaussianDiffusion(nn.Module):
             x = self.q_sample(x_start=norm_spec, t=torch.tensor([t - 1], device=device).long())
         x = x.reshape(b, self.out_dims, -1).contiguous()
         unet = self.denoise_fn.native()
-        betas = self._buf("betas")[:t]
         if method is not None and infer_speedup > 1:
             if method == "dpm-solver":
-                unet.sample("dpm-solver", dpm_table(betas, t // infer_speedup), cond, x)
+                unet.sample("dpm-solver", self._table(("dpm", t, infer_speedup), lambda: dpm_table(self._buf("betas")[:t], t // infer_speedup)), cond, x)
             elif method == "unipc":
-                unet.sample("unipc", unipc_table(betas, t // infer_speedup), cond, x)
+                unet.sample("unipc", self._table(("unipc", t, infer_speedup), lambda: unipc_table(self._buf("betas")[:t], t // infer_speedup)), cond, x)
             elif method == "pndm":
                 if b != 1:
                     # reference diffusion.py:155 `max(t - interval, 0)` on a batch tensor raises for B > 1
                     raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous")
-                unet.sample("pndm", self._plms_table(t, infer_speedup), cond, x)
+                unet.sample("pndm", self._table(("plms", t, infer_speedup), lambda: self._plms_table(t, infer_speedup)), cond, x)
             elif method == "ddim":
-                unet.sample("ddim", self._ddim_table(t, infer_speedup), cond, x)
+                unet.sample("ddim", self._table(("ddim", t, infer_speedup), lambda: self._ddim_table(t, infer_speedup)), cond, x)
             else:
                 raise NotImplementedError(method)
         else:
-            tab = self._ddpm_table(t)
+            tab = self._table(("ddpm", t), lambda: self._ddpm_table(t))
             chunk = 64
             for s0 in range(0, t, chunk):
                 n = min(chunk, t - s0)

@@ -122,6 +122,36 @@ def test_conv_dma(name):
     assert relmax(out, ref) < 2e-5, relmax(out, ref)
 
 
+@pytest.mark.parametrize("C,heads,T", [(64, 2, 72), (96, 2, 37), (128, 2, 50)])      # head dim 32 / 48 / 64; T % 4 = 0, 1, 2
+def test_conv_dma_value_layout(C, heads, T):
+    """QKV convolution: q, k leave in K4P, v in attention's VT layout [B][heads][ceil(T/4)][D][4] with a zeroed key tail"""
+    from lds import native
+    B, D = 2, C // heads
+    x = U(f"vt{C}.x", (B, 64, T), -2, 2)
+    w = U(f"vt{C}.w", (3 * C, 64, 1)) / np.float32(8.0)
+    ref = ref_dconv(x, w)
+    T4 = (T + 3) // 4 * 4
+    a = native.DConvTest()
+    dx = dev(x)
+    wk = np.ascontiguousarray(w, dtype=np.float32)
+    a.x1, a.x2, a.C1, a.C2, a.T = dx.data_ptr(), None, 64, 0, T
+    a.w, a.bias, a.Co, a.K, a.stride, a.pad, a.ups = wk.ctypes.data, None, 3 * C, 1, 1, 0, 0
+    a.res, a.epilogue, a.plain_out, a.v_split, a.cfg = None, 0, 0, D, 0
+    out = torch.full((B * 2 * C * T + B * C * T4,), float("nan"), dtype=torch.float32, device="cuda")
+    native.check(native.lib().lds_test_dconv(ct.byref(a), ct.c_void_p(out.data_ptr()), None, B, stream()))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    qk = o[:B * 2 * C * T].reshape(B, 2 * C, T)
+    vt = o[B * 2 * C * T:].reshape(B, heads, T4 // 4, D, 4)
+    assert relmax(qk, ref[:, :2 * C]) < 2e-5
+    v = np.zeros((B, C, T4), dtype=np.float32)
+    v[:, :, :T] = ref[:, 2 * C:]
+    want = v.reshape(B, heads, D, T4 // 4, 4).transpose(0, 1, 3, 2, 4)
+    assert np.isfinite(vt).all()
+    assert relmax(vt, want) < 2e-5
+    assert (vt.transpose(0, 1, 3, 2, 4).reshape(B, C, T4)[:, :, T:] == 0).all()
+
+
 def test_conv_dma_layernorm_partials():
     """the epilogue's per-frame (mean, M2) over each 32-channel tile"""
     B, C, T = 2, 128, 70
@@ -183,7 +213,9 @@ def test_layernorm_chain_k4p(C, Co, T, B):
     assert relmax(out.cpu().numpy(), ref) < 2e-5, relmax(out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("C,T,B", [(256, 64, 2), (256, 512, 1), (384, 256, 1), (384, 100, 2), (512, 128, 2), (512, 37, 1), (256, 130, 1)])
+# B * heads * ceil(T/128) >= 256 selects 128-query workgroups, T <= 32 single-wave ones, the rest 64-query ones
+@pytest.mark.parametrize("C,T,B", [(256, 64, 2), (256, 512, 1), (384, 256, 1), (384, 100, 2), (512, 128, 2), (512, 37, 1), (256, 130, 1),
+                                   (256, 512, 8), (384, 256, 16), (512, 128, 32), (256, 20, 2), (384, 32, 1)])
 def test_attention_k4p(C, T, B):
     from lds import native
     heads = 8
