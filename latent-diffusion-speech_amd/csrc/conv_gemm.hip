@@ -453,53 +453,114 @@ struct ConvKernel {
         }
     }
 
+    // Epilogue in phases: every load of a phase (row constants; then per-element residual / broadcast bias / accumulate
+    // operands of ALL tiles) is issued before the first store.  A load placed after a store cannot be moved above it
+    // (possible aliasing -- `accum` even reads the output buffer), and a load -> wait -> store chain per element costs
+    // one memory round trip each.
+    __device__ __forceinline__ bool elem(int i, int r, int n, bool geglu, int& co, long long& oi) const {
+        const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int orow = geglu ? (m0 + wm * 64) / 2 + rloc : m0 + wm * TM * 32 + i * 32 + rloc;
+        co = orow;
+        int to = n;
+        if (p.phases > 1) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
+        oi = ((long long)b * p.Cout + co) * p.Tout + to;
+        return co < p.Cout && n < p.To && to >= 0 && to < p.Tout;
+    }
+
     __device__ __forceinline__ void epilogue() {
         const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
+        const int ni = geglu ? 1 : TM;
+        if constexpr (NACC == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[0][i][j] += acc[NACC - 1][i][j];
+        }
+        if (p.bias) {
+            float kb[TM][16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kb[i][r] = p.bias[m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] += kb[i][r];
+        }
+        if (geglu) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = acc[0][TM - 1][j][r];
+                    acc[0][0][j][r] *= 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+                }
+        }
+        if (p.bias_bc || p.res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i >= ni) break;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = t0 + wn * TN * 32 + j * 32 + c;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co; long long oi;
+                        if (elem(i, r, n, geglu, co, oi)) {
+                            if (p.bias_bc) acc[0][i][j][r] += p.bias_bc[(long long)b * p.Cout + co];
+                            if (p.res) acc[0][i][j][r] += p.res[oi];
+                        }
+                    }
+                }
+            }
+        }
+        if (p.epi == EPI_TANH) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] = tanhf(acc[0][i][j][r]);
+        }
+        if (p.accum) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i >= ni) break;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = t0 + wn * TN * 32 + j * 32 + c;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co; long long oi;
+                        if (elem(i, r, n, geglu, co, oi)) acc[0][i][j][r] += p.out[oi];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (geglu && i == 1) break;
+            if (i >= ni) break;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
-                float vals[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int m = m0 + wm * TM * 32 + i * 32 + rloc;      // packed row
-                    float v = (NACC == 2) ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] : acc[0][i][j][r];
-                    int orow;
-                    if (geglu) {
-                        float g = acc[0][TM - 1][j][r];
-                        if (p.bias) { v += p.bias[m]; g += p.bias[m + 32]; }
-                        v = v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
-                        orow = (m0 + wm * 64) / 2 + rloc;
-                    } else {
-                        if (p.bias) v += p.bias[m];
-                        orow = m;
-                    }
-                    int co = orow, to = n;
-                    if (p.phases > 1) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
-                    if (co < p.Cout && n < p.To && to >= 0 && to < p.Tout) {
-                        if (p.bias_bc) v += p.bias_bc[(long long)b * p.Cout + co];
-                        const long long oi = ((long long)b * p.Cout + co) * p.Tout + to;
-                        if (p.res) v += p.res[oi];
-                        if (p.epi == EPI_TANH) v = tanhf(v);
-                        if (p.accum) v += p.out[oi];
-                        if (p.out_div != 1.0f) v = v / p.out_div;
-                        p.out[oi] = v;
-                    }
-                    vals[r] = v;
+                    if (p.out_div != 1.0f) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
+                    int co; long long oi;
+                    if (elem(i, r, n, geglu, co, oi)) p.out[oi] = acc[0][i][j][r];
                 }
                 if (p.lnpart_out) {
                     // (mean, M2) of this frame over the 32 output channels of this MFMA tile: 16 values in this lane,
                     // 16 in lane^32; combined with Chan's formula and consumed by the next layer's LayerNorm-on-load
                     float s = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += vals[r];
+                    for (int r = 0; r < 16; ++r) s += acc[0][i][j][r];
                     const float m16 = s * (1.0f / 16.0f);
                     float q = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float d = vals[r] - m16; q += d * d; }
+                    for (int r = 0; r < 16; ++r) { const float d = acc[0][i][j][r] - m16; q += d * d; }
                     const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(q, 32, 64);
                     const float d = mo - m16;
                     const float mean = 0.5f * (m16 + mo);
