@@ -496,8 +496,11 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
             cands[nc++] = {128, 128, 32, 2, 1.0};
             cands[nc++] = {128, 64, 32, 3, 0.97};
         } else {
-            if (a.Ci <= 512) cands[nc++] = {64, 64, 16, 3, 0.93};
-            else cands[nc++] = {64, 64, 64, 2, 0.93};
+            // short reductions: one resident wave of workgroups (<= 768) prefers BK 32 x 2 stages, a grid several waves deep the
+            // lighter BK 16 x 3 (more workgroups per CU to overlap prologues / epilogues); long ones few big stages
+            if (a.Ci > 512) cands[nc++] = {64, 64, 64, 2, 0.93};
+            else if (blocks(64, 64) <= 768) cands[nc++] = {64, 64, 32, 2, 0.93};
+            else cands[nc++] = {64, 64, 16, 3, 0.93};
             if (a.Mp % 128 == 0) cands[nc++] = {128, 64, 32, 2, 0.97};
         }
         double best = 1e300;
