@@ -34,8 +34,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
 struct DmaCfg {
-    static constexpr int WAVES_M = 2, WAVES_N = 2;
-    static constexpr int TM = BM / 64, TN = BN / 64;
+    // BM = 32: split-K inside the workgroup for grids smaller than the chip.  The tile is 32 x 64; waves (wn, ks) take
+    // column block wn and half ks of every K-step's k range, and the two partial sums meet through LDS in the epilogue
+    // (fixed order: ks = 0 adds the ks = 1 partial), so a 64 x 64 tile's work spreads over two workgroups / CUs.
+    static constexpr bool SPLIT = BM == 32;
+    static constexpr int TM = SPLIT ? 1 : BM / 64, TN = BN / 64;
     static constexpr int KR = BK / 4;                                   // staged k-rows per K-step
     static constexpr int XW = UPS ? (BN / 2 + 2) : ((BN - 1) * STRIDE + KT);   // window entries (frames) per k-row
     static constexpr int WI = KT * KR * BM / 64;                        // weight DMA wave-instructions per tile
@@ -43,7 +46,8 @@ struct DmaCfg {
     static constexpr int RPW = KR / 4;                                  // activation k-rows staged by each wave
     static constexpr int NXI = (RPW * XW + 63) / 64;                    // activation DMA wave-instructions per wave
     static constexpr int PER_TILE = WPW + NXI;                          // VMEM ops per wave per tile
-    static constexpr int G = KT * BK / 8;                               // MFMA groups per K-step (4 k-pairs each)
+    static constexpr int KQW = SPLIT ? BK / 16 : BK / 8;                // 8-channel k groups per tap handled by one wave
+    static constexpr int G = KT * KQW;                                  // MFMA groups per K-step and wave (4 k-pairs each)
     static constexpr int NB = (G % 3 == 0 && TM * TN < 4) ? 3 : 2;      // operand ring depth (divides G: slots keep their phase across K-steps)
     static constexpr int NACC = (TM * TN >= 2) ? 1 : 2;                 // independent accumulator chains per tile
     static constexpr int STAGE = KT * BK * BM + KR * XW * 4;            // floats
@@ -52,17 +56,20 @@ struct DmaCfg {
     static constexpr int OCC_LDS = (int)((160 * 1024) / LDS_BYTES);
     static constexpr int OCC = (TM * TN >= 4) ? (OCC_LDS < 2 ? OCC_LDS : 2) : (OCC_LDS < 4 ? (OCC_LDS < 1 ? 1 : OCC_LDS) : 4);
     static_assert(WI % 4 == 0 && KR % 4 == 0, "tile does not split evenly over 4 waves");
+    static_assert(!SPLIT || (BN == 64 && BK % 16 == 0), "split-K tile is 32 x 64");
 };
 
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
 struct DmaKernel {
     using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, KR = Cfg::KR, XW = Cfg::XW, WPW = Cfg::WPW, RPW = Cfg::RPW, NXI = Cfg::NXI;
-    static constexpr int G = Cfg::G, NB = Cfg::NB, NACC = Cfg::NACC, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE;
+    static constexpr int G = Cfg::G, NB = Cfg::NB, NACC = Cfg::NACC, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE, KQW = Cfg::KQW;
+    static constexpr bool SPLIT = Cfg::SPLIT;
 
     const DmaConvArgs& p;
     float* smem;
-    int lane, wave, c, h, wm, wn, b, m0, t0;
+    int lane, wave, c, h, wm, wn, ks, b, m0, t0;
+    int kofs_a, kofs_b;       // split-K: float offsets of this wave's half of the staged k rows (weights / activations)
     int woff[WPW];            // per-lane byte offsets of this wave's weight chunks (loop invariant)
     int xoff[NXI];            // per-lane byte offsets of this wave's activation chunks inside a source slab
     __amdgpu_buffer_rsrc_t rw, rx1, rx2;   // packed weights; this batch element's slab of either source
@@ -80,7 +87,8 @@ struct DmaKernel {
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         c = lane & 31; h = lane >> 5;
-        wm = wave >> 1; wn = wave & 1;
+        wm = SPLIT ? 0 : wave >> 1; ks = SPLIT ? wave >> 1 : 0; wn = wave & 1;
+        kofs_a = ks * KQW * 2 * BM * 4; kofs_b = ks * KQW * 2 * XW * 4;
         // XCD-aware tile order.  Workgroups are dispatched in linear order, round-robin over the 8 XCDs, each with a private
         // L2.  The workgroups that read the same activation window (all M-blocks of one (batch, frame-block)) are given
         // consecutive slots of ONE XCD, so the window is fetched from the fabric once instead of once per XCD.
@@ -150,8 +158,8 @@ struct DmaKernel {
 
     template <int SLOT>
     __device__ __forceinline__ void load_ops(const float* st, int tap, int kq) {
-        const float* wt = st + ((tap * KR + kq * 2 + h) * BM + arow) * 4;
-        const float* xs = st + KT * BK * BM + (kq * 2 + h) * XW * 4;
+        const float* wt = st + ((tap * KR + kq * 2 + h) * BM + arow) * 4 + kofs_a;
+        const float* xs = st + KT * BK * BM + (kq * 2 + h) * XW * 4 + kofs_b;
 #pragma unroll
         for (int i = 0; i < TM; ++i) aop[SLOT][i] = *reinterpret_cast<const f32x4*>(wt + i * 32 * 4);
 #pragma unroll
@@ -173,7 +181,7 @@ struct DmaKernel {
     template <int g0, int g1>
     __device__ __forceinline__ void preload(const float* cur) {
         if constexpr (g0 < g1 && g0 < G) {
-            load_ops<g0 % NB>(cur, g0 / (BK / 8), g0 % (BK / 8));
+            load_ops<g0 % NB>(cur, g0 / KQW, g0 % KQW);
             preload<g0 + 1, g1>(cur);
         }
     }
@@ -193,11 +201,11 @@ struct DmaKernel {
         if constexpr (g < G) {
             constexpr int gp = g + NB - 1;                     // group whose operands are fetched now
             if constexpr (gp < G) {
-                load_ops<gp % NB>(cur, gp / (BK / 8), gp % (BK / 8));
+                load_ops<gp % NB>(cur, gp / KQW, gp % KQW);
             } else {
                 if (kc + 1 < nk) {
                     if constexpr (gp == G) tile_sync(kc, nk, cur);
-                    load_ops<gp % NB>(nxt, (gp - G) / (BK / 8), (gp - G) % (BK / 8));
+                    load_ops<gp % NB>(nxt, (gp - G) / KQW, (gp - G) % KQW);
                 }
             }
             mfma_ops<g % NB>();
@@ -400,8 +408,28 @@ struct DmaKernel {
         return geglu ? (m0 + wm * 64) / 2 : (m0 + wm * TM * 32 + i * 32);
     }
 
+    // split-K: the ks = 1 waves hand their partial tile to the ks = 0 wave of the same column block through LDS
+    __device__ __forceinline__ bool join_halves() {
+        if constexpr (NACC == 2) acc[0][0][0] += acc[1][0][0];
+        __syncthreads();                                   // every wave is done reading operand tiles: the stages are free
+        float* red = smem + wn * 16 * 64 + lane;
+        if (ks == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64] = acc[0][0][0][r];
+        }
+        __syncthreads();
+        if (ks == 1) return false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][0][r] += red[r * 64];
+        if constexpr (NACC == 2) acc[1][0][0] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        return true;
+    }
+
     __device__ __forceinline__ void epilogue() {
         const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
+        if constexpr (SPLIT) {
+            if (!join_halves()) return;
+        }
         finalize(geglu);
         const int ni = geglu ? 1 : TM;
         if (p.res) {
@@ -479,6 +507,10 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
     int bm, bn, bk, nst;
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
+    } else if (a.stride == 1 && !a.ups && a.epi != EPI_GEGLU && k32 && blocks(64, 64) <= 256) {
+        // fewer 64 x 64 tiles than CUs (the T/8 and T/4 levels at small batch): 32 x 64 tiles with the K range split over the
+        // workgroup's two wave pairs put twice as many CUs to work (tools/bench_dconv.py: 1.6x at 128 tiles, ~1.1x at 256)
+        bm = 32; bn = 64; bk = (a.KT == 1 && k64) ? 64 : 32; nst = 2;
     } else {
         // Pick the tile by a small occupancy model fitted to tools/bench_dconv.py sweeps: a CU runs its n workgroups r at a
         // time (r = LDS residency, <= 4); r >= 3 co-resident workgroups keep the matrix pipe full, 2 reach ~0.9, a lone one
@@ -538,6 +570,9 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
             if (bk == 32 && nst == 5) DCASE(64, 64, 1, 1, false, 32, 5);
             if (bk == 16 && nst == 4) DCASE(64, 64, 1, 1, false, 16, 4);
             if (bk == 16 && nst == 6) DCASE(64, 64, 1, 1, false, 16, 6);
+        } else if (tk == 32064) {
+            if (bk == 64) DCASE(32, 64, 1, 1, false, 64, 2);
+            if (bk == 32) DCASE(32, 64, 1, 1, false, 32, 2);
         } else if (tk == 128064) {
             if (bk == 32 && nst == 2) DCASE(128, 64, 1, 1, false, 32, 2);
             if (bk == 32 && nst == 3) DCASE(128, 64, 1, 1, false, 32, 3);
@@ -560,6 +595,8 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
             if (bk == 16 && nst == 3) DCASE(64, 64, 3, 1, false, 16, 3);
             if (bk == 16 && nst == 4) DCASE(64, 64, 3, 1, false, 16, 4);
             if (bk == 32 && nst == 4) DCASE(64, 64, 3, 1, false, 32, 4);
+        } else if (tk == 32064) {
+            if (bk == 32) DCASE(32, 64, 3, 1, false, 32, 2);
         } else if (tk == 128064) {
             if (bk == 16 && nst == 2) DCASE(128, 64, 3, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(128, 64, 3, 1, false, 16, 3);

@@ -95,6 +95,11 @@ DCASES = {
     "nst3_k3": (2, 64, 0, 100, 64, 3, dict(pad=1, bias=True, res=True, cfg=64064323)),
     "nst3_1x1_bk16": (1, 256, 0, 64, 64, 1, dict(cfg=64064163)),
     "nst2_1x1_deepk": (1, 1024, 0, 64, 64, 1, dict(cfg=64064642)),
+    # split-K inside the workgroup (32 x 64 tile, two wave pairs each take half of every K-step)
+    "split_1x1": (2, 128, 0, 50, 96, 1, dict(bias=True, res=True, cfg=32064322)),
+    "split_1x1_bk64": (1, 256, 0, 64, 64, 1, dict(bias=True, cfg=32064642)),
+    "split_k3": (2, 64, 0, 37, 128, 3, dict(pad=1, bias=True, res=True, cfg=32064322)),
+    "split_k3_concat": (1, 64, 96, 64, 64, 3, dict(pad=1, cfg=32064322)),
 }
 
 
