@@ -32,6 +32,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// erf for the GEGLU epilogue (reference activations.py GEGLU -> F.gelu, exact form).  Abramowitz & Stegun 7.1.26:
+// |error| <= 1.5e-7 absolute, i.e. at the level of fp32 rounding of erf itself; one v_rcp_f32, one v_exp_f32 and seven
+// multiply-adds instead of the ~40-instruction library routine -- the epilogue's vector work is paid in matrix time.
+static __device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+    return copysignf(fmaf(-pl * t, e, 1.0f), x);
+}
+
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
 struct DmaCfg {
     // BM = 32: split-K inside the workgroup for grids smaller than the chip.  The tile is 32 x 64; waves (wn, ks) take
@@ -311,7 +325,7 @@ struct DmaKernel {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float g = acc[0][TM - 1][j][r];
-                    acc[0][0][j][r] *= 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+                    acc[0][0][j][r] *= 0.5f * g * (1.0f + erf_fast(g * 0.70710678118654752440f));
                 }
         }
     }
@@ -525,8 +539,9 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
             cands[nc++] = {64, 64, 32, 2, 0.93};
             if (a.Mp % 128 == 0) cands[nc++] = {128, 128, 16, 2, 1.0};
         } else if (a.epi == EPI_GEGLU) {
-            cands[nc++] = {128, 128, 32, 2, 1.0};
-            cands[nc++] = {128, 64, 32, 3, 0.97};
+            // measured (tools/bench_dconv.py ff1_*): the 128 x 128 tile wins whenever a frame block is not half empty
+            if (a.To > 64) cands[nc++] = {128, 128, a.Ci >= 384 ? 16 : 32, 2, 1.0};
+            else cands[nc++] = {128, 64, 32, 2, 0.97};
         } else {
             // short reductions: one resident wave of workgroups (<= 768) prefers BK 32 x 2 stages, a grid several waves deep the
             // lighter BK 16 x 3 (more workgroups per CU to overlap prologues / epilogues); long ones few big stages
