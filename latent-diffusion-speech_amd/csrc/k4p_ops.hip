@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(256) resample_k4p_kernel(const float* __restri
     }
 }
 hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s) {
+    ProfScope ps(s, "resample", 0.0, 4.0 * B * (double)C * (Tin + Tout));
     hipLaunchKernelGGL(resample_k4p_kernel, dim3((unsigned)((long long)B * C / 4)), dim3(256), 0, s, in, out, Tin, Tout);
     return hipGetLastError();
 }

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(256) fill_kernel(float* p, float v, long long 
 hipError_t launch_fill(float* p, float v, long long n, hipStream_t s) {
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    ProfScope ps(s, "fill", 0.0, 4.0 * (double)n);
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, v, n);
     return hipGetLastError();
 }

@@ -45,25 +45,48 @@ extern "C" int lds_version(void) { return 1; }
 // ------------------------------------------------------------------------------------------------
 // event profiler (off by default; bench.py turns it on for one instrumented pass)
 // ------------------------------------------------------------------------------------------------
-struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
-static bool g_prof_on = false;
+// One event marks each launch boundary.  Inside lds_sampler_run every launch is wrapped, so consecutive scopes share the
+// boundary event (a kernel's stop is the next kernel's start): an interval is that kernel's execution plus its own dispatch,
+// not two event packets per kernel.
+struct ProfRec { std::string name; double flops, bytes; int ia, ib; };
+static bool g_prof_on = false, g_prof_chain = false;
 static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_ev;
+static hipStream_t g_prof_last_stream = nullptr;
+static int g_prof_last_stop = -1;
 
+static int prof_mark(hipStream_t st) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    (void)hipEventRecord(e, st);
+    g_prof_ev.push_back(e);
+    return (int)g_prof_ev.size() - 1;
+}
 lds::ProfScope::ProfScope(hipStream_t st, const char* name, double flops, double bytes) : on(g_prof_on), s(st) {
     if (!on) return;
     ProfRec r;
-    r.name = name; r.flops = flops; r.bytes = bytes;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
-    (void)hipEventRecord(r.a, st);
+    r.name = name; r.flops = flops; r.bytes = bytes; r.ib = -1;
+    r.ia = (g_prof_chain && g_prof_last_stop >= 0 && g_prof_last_stream == st) ? g_prof_last_stop : prof_mark(st);
+    if (r.ia < 0) { on = false; return; }
     g_prof.push_back(r);
 }
 lds::ProfScope::~ProfScope() {
-    if (on) (void)hipEventRecord(g_prof.back().b, s);
+    if (!on) return;
+    g_prof.back().ib = prof_mark(s);
+    g_prof_last_stop = g_prof.back().ib;
+    g_prof_last_stream = s;
 }
+struct ProfChain {      // RAII: boundary events are shared while alive
+    bool prev;
+    ProfChain() : prev(g_prof_chain) { g_prof_chain = true; g_prof_last_stop = -1; }
+    ~ProfChain() { g_prof_chain = prev; g_prof_last_stop = -1; }
+};
 
 extern "C" int lds_prof_enable(int on) {
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
+    g_prof_ev.clear();
     g_prof.clear();
+    g_prof_last_stop = -1;
     g_prof_on = on != 0;
     return LDS_OK;
 }
@@ -74,7 +97,7 @@ extern "C" int lds_prof_summary(char* buf, size_t cap) {
     std::map<std::string, Agg> agg;
     for (auto& r : g_prof) {
         float ms = 0.f;
-        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+        if (r.ib < 0 || hipEventSynchronize(g_prof_ev[r.ib]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[r.ia], g_prof_ev[r.ib]) != hipSuccess)
             return fail(LDS_EHIP, "profiler event read failed");
         Agg& a = agg[r.name];
         a.n++; a.ms += ms; a.fl += r.flops; a.by += r.bytes;
@@ -844,6 +867,7 @@ extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float*
                                const float* noise, void* ws, size_t ws_bytes, int B, int T, void* stream) {
     if (!u || !table || !cond || !x || !ws || n_rows <= 0 || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
+    ProfChain chain;
     Arena A(ws, ws_bytes);
     SampWs s;
     plan_samp(u, A, B, T, s);
