@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int D, int NW, int NST>
+template <int D, int NW, int NST, int KS = 1>
 struct AttCfg {
     static constexpr int KB = 64;                       // keys per tile
     static constexpr int DQ = D / 8, DT = (D + 31) / 32;
@@ -35,6 +35,12 @@ struct AttCfg {
     static constexpr size_t LDS_BYTES = (size_t)NST * STAGE * sizeof(float) + 256;
     static_assert(KROWS % NW == 0 && VCH % NW == 0, "tile must split evenly over the waves");
 };
+
+static __device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 template <int Y, int PER_TILE>
 static __device__ __forceinline__ void att_wait_younger(int y) {
@@ -49,8 +55,8 @@ static __device__ __forceinline__ void att_wait_younger(int y) {
 
 // tile kt -> LDS stage `st`: this wave's share of the K rows and of the V chunks (1 KB per instruction)
 template <int D, int NW, int KPW, int VPW>
-static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc_t rk, const __amdgpu_buffer_rsrc_t rv, const int (&koff)[KPW],
-                                                      const int (&voff)[VPW], int wave, int kt, float* st) {
+static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc_t rk, const __amdgpu_buffer_rsrc_t rv, const int* koff,
+                                                      const int* voff, int wave, int kt, float* st) {
 #pragma unroll
     for (int i = 0; i < KPW; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 256), 16, koff[i], kt * (64 * 16), 0, 0);
@@ -60,10 +66,13 @@ static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc
                                                  kt * (64 * D * 4), 0, 0);
 }
 
-template <int D, int NW, int NST>
+// KS = 2 (short sequences): the workgroup covers (NW/2)*32 queries and its two wave groups each take one 32-key half of every
+// staged tile, so twice as many waves share the work; the partial (max, sum, output) triples meet through LDS at the end.
+template <int D, int NW, int NST, int KS>
 __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ out,
                                                                 int C, int T, float scale2) {
-    using Cfg = AttCfg<D, NW, NST>;
+    using Cfg = AttCfg<D, NW, NST, KS>;
+    constexpr int NWQ = NW / KS;
     constexpr int KB = Cfg::KB, DQ = Cfg::DQ, DT = Cfg::DT, KPW = Cfg::KPW, VPW = Cfg::VPW, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // NST x { K [row][key][4] ; V [keyquad][d][4] }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -75,7 +84,8 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     const int per = total >> 3, rem = total & 7, xcd = id & 7;
     const int L = xcd * per + (xcd < rem ? xcd : rem) + (id >> 3);
     const int qblk = L % gx, hd = (L / gx) % gy, b = L / (gx * gy);
-    const int tq = qblk * (NW * 32) + wave * 32 + c;
+    const int qw = wave % NWQ, ks = wave / NWQ;       // query tile of this wave; which 32-key half of each tile it takes
+    const int tq = qblk * (NWQ * 32) + qw * 32 + c;
     const int Tp = T + 2, T4 = (T + 3) & ~3;
     const float* qb = qk + ((long long)b * 2 * C + (long long)hd * D) * Tp;            // q rows of this head
 
@@ -98,7 +108,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < VPW; ++i) voff[i] = ((wave + NW * i) * 64 + lane) * 16;
     const int nt = (T + KB - 1) / KB;
-    for (int t = 0; t < NST - 1 && t < nt; ++t) att_issue_tile<D, NW>(rk, rv, koff, voff, wave, t, smem + t * STAGE);
+    for (int t = 0; t < NST - 1 && t < nt; ++t) att_issue_tile<D, NW, KPW, VPW>(rk, rv, koff, voff, wave, t, smem + t * STAGE);
 #pragma unroll
     for (int kq = 0; kq < DQ; ++kq) qv[kq] *= scale2;
 
@@ -116,63 +126,106 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         att_wait_younger<NST - 2, PER_TILE>(younger);
         __builtin_amdgcn_s_barrier();              // every wave's share landed; every wave is done with the stage refilled below
         asm volatile("" ::: "memory");
-        if (kt + NST - 1 < nt) att_issue_tile<D, NW>(rk, rv, koff, voff, wave, kt + NST - 1, smem + sn * STAGE);
+        if (kt + NST - 1 < nt) att_issue_tile<D, NW, KPW, VPW>(rk, rv, koff, voff, wave, kt + NST - 1, smem + sn * STAGE);
         const float* Kc = smem + sc * STAGE;
         const float* Vc = Kc + KB * D;
 #pragma unroll 1
-        for (int half = 0; half < KB / 32; ++half) {
+        for (int half = (KS == 2 ? ks : 0); half < (KS == 2 ? ks + 1 : KB / 32); ++half) {
             const int kbase = kt * KB + half * 32;
             if (kbase >= T) break;
+            // operands are fetched ahead of their use and pinned there: all K operands before the first QK MFMA, all V operands
+            // behind the QK MFMAs so their LDS latency hides under those and the softmax
+            f32x4 ka[DQ], va[4][DT];
+#pragma unroll
+            for (int kq = 0; kq < DQ; ++kq) ka[kq] = *reinterpret_cast<const f32x4*>(Kc + ((kq * 2 + h) * KB + half * 32 + c) * 4);
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-            for (int kq = 0; kq < DQ; ++kq) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(Kc + ((kq * 2 + h) * KB + half * 32 + c) * 4);
+            for (int kq = 0; kq < DQ; ++kq)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], qv[kq][jj], s, 0, 0, 0);
-            }
+                for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kq][jj], qv[kq][jj], s, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+                    // V[d = i*32 + c][keys 8g+4h .. +3]; rows d >= D (second tile of D = 48) read a neighbour's entries and
+                    // only feed output rows that are never stored
+                    va[g][i] = *reinterpret_cast<const f32x4*>(Vc + ((half * 8 + 2 * g + h) * D + i * 32 + c) * 4);
+            __builtin_amdgcn_sched_barrier(0);
             // all of this VALU work is paid in matrix time on gfx950 (the fp32 MFMA shares the vector ALU): one v_exp_f32
-            // per score, the key mask only in the ragged last tile, the rescale only when some running maximum moved
+            // per score, packed subtract / add / multiply, the key mask only in the ragged last tile
             if (kbase + 32 > T) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kbase + (r & 3) + 8 * (r >> 2) + 4 * h >= T) s[r] = -INFINITY;
             }
-            float mt = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            // tile maximum per query: seven v_max3 (no NaN canonicalisation), the other 16 keys sit in lane ^ 32
+            float mt = max3(max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[8])),
+                            max3(max3(s[9], s[10], s[11]), max3(s[12], s[13], s[14]), s[15]), m_run);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+                mt = max3(mt, __uint_as_float(sw[0]), __uint_as_float(sw[1]));      // one of the two is this lane's own value
+            }
+            // branch-free online softmax: alpha = 1 when the maximum did not move (a wave-uniform skip of the rescale costs
+            // more in register copies at the join than the 8 packed multiplies it saves)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - mt);
+            m_run = mt;
+            const f32x2 mm = {mt, mt}, aa = {alpha, alpha};
+            f32x2 lsum = {0.f, 0.f};
 #pragma unroll
-            for (int r = 4; r < 16; r += 2) mt = fmaxf(mt, fmaxf(s[r], s[r + 1]));
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m_run, mt);
-            float ls = 0.f;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 d = f32x2{s[r], s[r + 1]} - mm;
+                s[r] = __builtin_amdgcn_exp2f(d[0]);
+                s[r + 1] = __builtin_amdgcn_exp2f(d[1]);
+                lsum += f32x2{s[r], s[r + 1]};
+            }
+            l_run = fmaf(l_run, alpha, lsum[0] + lsum[1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
-            if (__any(m_new != m_run)) {             // wave-uniform
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                l_run *= alpha;
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 t = f32x2{o[i][r], o[i][r + 1]} * aa;
+                    o[i][r] = t[0]; o[i][r + 1] = t[1];
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < DT; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-                m_run = m_new;
-            }
-            l_run += ls;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int i = 0; i < DT; ++i) {
-                    // V[d = i*32 + c][keys 8g+4h .. +3]; rows d >= D (second tile of D = 48) read a neighbour's entries and
-                    // only feed output rows that are never stored
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(Vc + ((half * 8 + 2 * g + h) * D + i * 32 + c) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], s[4 * g + e], o[i], 0, 0, 0);
-                }
-            }
+                    for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g][i][e], s[4 * g + e], o[i], 0, 0, 0);
         }
         sc = (sc + 1 == NST) ? 0 : sc + 1;
         sn = (sn + 1 == NST) ? 0 : sn + 1;
     }
-    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    if constexpr (KS == 2) {
+        // join the two key halves: (m, l, o) of the ks = 1 wave into its ks = 0 partner, fixed order
+        __syncthreads();                                   // all waves are done with the K/V stages
+        float* red = smem + qw * (2 + 16 * DT) * 64 + lane;
+        if (ks == 1) {
+            red[0] = m_run; red[64] = l_run;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(2 + i * 16 + r) * 64] = o[i][r];
+        }
+        __syncthreads();
+        if (ks == 1) return;
+        const float m1 = red[0], l1 = red[64];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);      // a1 = 0 when the other half saw no key
+        l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + red[(2 + i * 16 + r) * 64] * a1;
+    }
+    float l;
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // own + partner (each appears once)
+    }
     if (tq < T) {
         const float rl = 1.0f / l;
         float* ob = out + (long long)b * C * Tp;
@@ -193,28 +246,31 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     }
 }
 
-template <int D, int NW, int NST>
+template <int D, int NW, int NST, int KS>
 static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, hipStream_t s) {
-    using Cfg = AttCfg<D, NW, NST>;
-    auto kern = attention_k4p_kernel<D, NW, NST>;
+    using Cfg = AttCfg<D, NW, NST, KS>;
+    auto kern = attention_k4p_kernel<D, NW, NST, KS>;
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((T + NW * 32 - 1) / (NW * 32), heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);
+    constexpr int QPB = NW / KS * 32;       // queries per workgroup
+    hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);
     return hipGetLastError();
 }
 
 template <int D>
 static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
     const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
-    // queries per workgroup: 128 (four waves share each K/V tile) when that still gives every CU a workgroup, else 64
-    // (32 for a single tile)
-    if ((long long)((T + 127) / 128) * heads * B >= 256) return launch_cfg<D, 4, (D == 64 ? 2 : 3)>(qk, vt, out, B, C, T, heads, scale, s);
-    if (T > 32) return launch_cfg<D, 2, (D == 64 ? 2 : 3)>(qk, vt, out, B, C, T, heads, scale, s);
-    return launch_cfg<D, 1, 2>(qk, vt, out, B, C, T, heads, scale, s);
+    constexpr int NST = (D == 64) ? 2 : 3;
+    const long long hb = (long long)heads * B;
+    // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
+    // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
+    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1>(qk, vt, out, B, C, T, heads, scale, s);
+    if (T > 32) return launch_cfg<D, 4, NST, 2>(qk, vt, out, B, C, T, heads, scale, s);
+    return launch_cfg<D, 1, 2, 1>(qk, vt, out, B, C, T, heads, scale, s);
 }
 
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
