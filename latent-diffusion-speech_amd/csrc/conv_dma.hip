@@ -93,6 +93,11 @@ struct DmaKernel {
     f32x16 acc[NACC][TM][TN];
     f32x4 aop[NB][TM], bop[NB][TN];
     float lmu[TN], lrs[TN];   // folded input-LayerNorm statistics of this lane's output columns
+    // single-tile waves fetch the epilogue's operands at kernel start (16 + 16 registers): the residual entries and the bias
+    // rows have landed long before the main loop ends, so the epilogue begins without a memory round trip
+    static constexpr bool EARLY = TM * TN == 1;
+    f32x2 rsv[EARLY ? 8 : 1];
+    float kbv[EARLY ? 16 : 1];
 
     __device__ __forceinline__ DmaKernel(const DmaConvArgs& p_, float* s_) : p(p_), smem(s_) {}
 
@@ -271,9 +276,27 @@ struct DmaKernel {
         }
     }
 
+    __device__ __forceinline__ bool res_tile(int tile0, int n) const {
+        return p.res && !p.out_plain && tile0 < p.plain_from && tile0 < p.Cout && n < p.To;
+    }
+    __device__ __forceinline__ void early_loads() {
+        const int tile0 = m0 + wm * TM * 32, n = t0 + wn * TN * 32 + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rsv[e] = f32x2{0.f, 0.f};
+        if (res_tile(tile0, n)) {
+            const int Tpo = p.To + 2;
+            const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rsv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kbv[r] = (p.bias && !p.ln_part) ? p.bias[tile0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    }
+
     __device__ __forceinline__ void mainloop() {
         static_assert(G % NB == 0 && NB - 1 <= G, "ring slots must keep their phase across K-steps");
         const int nk = p.Ci / BK;
+        if constexpr (EARLY) early_loads();
         for (int t = 0; t < NST && t < nk; ++t) issue_tile(t, smem + t * STAGE);
         if (p.ln_part) ln_columns();
         wait_younger<NST - 1>((nk - 1 < NST - 1) ? nk - 1 : NST - 1);      // tile 0 landed (this wave's share)
@@ -299,7 +322,10 @@ struct DmaKernel {
                 for (int j = 0; j < TN; ++j) acc[0][i][j] += acc[1][i][j];
         }
         const bool ln = p.ln_part != nullptr;
-        if (ln || p.bias) {
+        if (EARLY && !ln) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][0][r] += kbv[r];
+        } else if (ln || p.bias) {
             float k1[TM][16], k2[TM][16];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -367,11 +393,16 @@ struct DmaKernel {
     // phase 2: residual add (all loads in flight together, before any store)
     __device__ __forceinline__ void add_residual(int tile0, int i, int j, int n) {
         if (n >= p.To) return;
-        const int Tpo = p.To + 2;
-        const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
         f32x2 rv[8];
+        if constexpr (EARLY) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
+            for (int e = 0; e < 8; ++e) rv[e] = rsv[e];
+        } else {
+            const int Tpo = p.To + 2;
+            const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
