@@ -453,20 +453,99 @@ struct ConvKernel {
         }
     }
 
-    // Epilogue in phases: every load of a phase (row constants; then per-element residual / broadcast bias / accumulate
-    // operands of ALL tiles) is issued before the first store.  A load placed after a store cannot be moved above it
-    // (possible aliasing -- `accum` even reads the output buffer), and a load -> wait -> store chain per element costs
-    // one memory round trip each.
+    // PH: polyphase (ConvTranspose) output mapping.  A template flag, like every other wave-uniform condition below it is
+    // kept OUT of the per-element loops: a branch inside them splits the loop body into basic blocks and the loads of
+    // different elements can then no longer be issued together.
+    template <bool PH>
     __device__ __forceinline__ bool elem(int i, int r, int n, bool geglu, int& co, long long& oi) const {
         const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int orow = geglu ? (m0 + wm * 64) / 2 + rloc : m0 + wm * TM * 32 + i * 32 + rloc;
         co = orow;
         int to = n;
-        if (p.phases > 1) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
+        if constexpr (PH) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
         oi = ((long long)b * p.Cout + co) * p.Tout + to;
         return co < p.Cout && n < p.To && to >= 0 && to < p.Tout;
     }
 
+    // acc[0] += src[index] for every valid element of every tile: unconditional loads from a clamped index + select
+    template <bool PH, bool PER_CO>
+    __device__ __forceinline__ void add_from(const float* src, bool geglu, int ni) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i >= ni) break;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = t0 + wn * TN * 32 + j * 32 + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co; long long oi;
+                    const bool ok = elem<PH>(i, r, n, geglu, co, oi);
+                    const long long idx = PER_CO ? (long long)b * p.Cout + co : oi;
+                    const float v = src[ok ? idx : 0];
+                    acc[0][i][j][r] += ok ? v : 0.f;
+                }
+            }
+        }
+    }
+
+    template <bool PH>
+    __device__ __forceinline__ void epilogue_tail(bool geglu, int ni) {
+        if (p.bias_bc) add_from<PH, true>(p.bias_bc, geglu, ni);
+        if (p.res) add_from<PH, false>(p.res, geglu, ni);
+        if (p.epi == EPI_TANH) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] = tanhf(acc[0][i][j][r]);
+        }
+        if (p.accum) add_from<PH, false>(p.out, geglu, ni);
+        if (p.out_div != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i >= ni) break;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = t0 + wn * TN * 32 + j * 32 + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co; long long oi;
+                    if (elem<PH>(i, r, n, geglu, co, oi)) p.out[oi] = acc[0][i][j][r];
+                }
+                if (p.lnpart_out) {
+                    // (mean, M2) of this frame over the 32 output channels of this MFMA tile: 16 values in this lane,
+                    // 16 in lane^32; combined with Chan's formula and consumed by the next layer's LayerNorm-on-load
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc[0][i][j][r];
+                    const float m16 = s * (1.0f / 16.0f);
+                    float q = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = acc[0][i][j][r] - m16; q += d * d; }
+                    const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(q, 32, 64);
+                    const float d = mo - m16;
+                    const float mean = 0.5f * (m16 + mo);
+                    const float m2 = (q + qo) + d * d * 8.0f;
+                    const int tile32 = (m0 + wm * TM * 32 + i * 32) >> 5;
+                    if (h == 0 && n < p.To && tile32 * 32 < p.Cout)
+                        p.lnpart_out[((long long)b * (p.Cout >> 5) + tile32) * p.Tout + n] = make_float2(mean, m2);
+                }
+            }
+        }
+    }
+
+    // Epilogue in phases: every load of a phase (row constants; then per-element residual / broadcast bias / accumulate
+    // operands of ALL tiles) is issued before the first store.  A load placed after a store cannot be moved above it
+    // (possible aliasing -- `accum` even reads the output buffer), and a load -> wait -> store chain per element costs
+    // one memory round trip each.
     __device__ __forceinline__ void epilogue() {
         const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
         const int ni = geglu ? 1 : TM;
@@ -498,79 +577,8 @@ struct ConvKernel {
                     acc[0][0][j][r] *= 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
                 }
         }
-        if (p.bias_bc || p.res) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i >= ni) break;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = t0 + wn * TN * 32 + j * 32 + c;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int co; long long oi;
-                        if (elem(i, r, n, geglu, co, oi)) {
-                            if (p.bias_bc) acc[0][i][j][r] += p.bias_bc[(long long)b * p.Cout + co];
-                            if (p.res) acc[0][i][j][r] += p.res[oi];
-                        }
-                    }
-                }
-            }
-        }
-        if (p.epi == EPI_TANH) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] = tanhf(acc[0][i][j][r]);
-        }
-        if (p.accum) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i >= ni) break;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = t0 + wn * TN * 32 + j * 32 + c;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int co; long long oi;
-                        if (elem(i, r, n, geglu, co, oi)) acc[0][i][j][r] += p.out[oi];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (i >= ni) break;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = t0 + wn * TN * 32 + j * 32 + c;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (p.out_div != 1.0f) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
-                    int co; long long oi;
-                    if (elem(i, r, n, geglu, co, oi)) p.out[oi] = acc[0][i][j][r];
-                }
-                if (p.lnpart_out) {
-                    // (mean, M2) of this frame over the 32 output channels of this MFMA tile: 16 values in this lane,
-                    // 16 in lane^32; combined with Chan's formula and consumed by the next layer's LayerNorm-on-load
-                    float s = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[0][i][j][r];
-                    const float m16 = s * (1.0f / 16.0f);
-                    float q = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float d = acc[0][i][j][r] - m16; q += d * d; }
-                    const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(q, 32, 64);
-                    const float d = mo - m16;
-                    const float mean = 0.5f * (m16 + mo);
-                    const float m2 = (q + qo) + d * d * 8.0f;
-                    const int tile32 = (m0 + wm * TM * 32 + i * 32) >> 5;
-                    if (h == 0 && n < p.To && tile32 * 32 < p.Cout)
-                        p.lnpart_out[((long long)b * (p.Cout >> 5) + tile32) * p.Tout + n] = make_float2(mean, m2);
-                }
-            }
-        }
+        if (p.phases > 1) epilogue_tail<true>(geglu, ni);
+        else epilogue_tail<false>(geglu, ni);
     }
 };
 

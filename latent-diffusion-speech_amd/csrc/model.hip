@@ -307,6 +307,12 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
         std::string cfgs(c);
         size_t p = cfgs.find(" grid");
         g_prof.back().name = "conv_gemm<" + cfgs.substr(0, p) + ">";
+        static const bool shapes = getenv("LDS_PROF_SHAPES") != nullptr;      // per-shape breakdown for tuning sessions
+        if (shapes) {
+            char sh[96];
+            snprintf(sh, sizeof(sh), " Ci%d Co%d K%d d%d To%d%s%s", W.Ci, W.Co, W.K, o.dil, a.To, o.phases > 1 ? " convT" : "", o.res ? " +res" : "");
+            g_prof.back().name += sh;
+        }
     }
     if (e != hipSuccess)
         return fail(LDS_EHIP, "conv_gemm launch failed (%s): Co %d Ci %d K %d stride %d dil %d ups %d To %d", hipGetErrorString(e), W.Co,
