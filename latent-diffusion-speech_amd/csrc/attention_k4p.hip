@@ -265,7 +265,8 @@ template <int D>
 static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
     const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
     constexpr int NST = (D == 64) ? 2 : 3;
-    const long long hb = (long long)heads * B;
+    // judged at the nominal per-GPU batch (16): the choice fixes the summation order, which must not depend on the batch size
+    const long long hb = (long long)heads * 16;
     // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
     // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
     if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1>(qk, vt, out, B, C, T, heads, scale, s);

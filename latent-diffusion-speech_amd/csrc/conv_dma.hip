@@ -548,7 +548,11 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
     static const int env_cfg = getenv("LDS_DMA_CFG") ? atoi(getenv("LDS_DMA_CFG")) : 0;     // experiments only
     if (cfg == 0) cfg = env_cfg;
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
-    auto blocks = [&](int bm, int bn) -> long long { return (a.Mp % bm) ? -1 : (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B; };
+    // The tile shape fixes the order of the K reduction, so it must not depend on the batch size: an utterance's result is then
+    // bit-identical for any batch split.  Grid sizes are therefore judged at the nominal per-GPU batch of
+    // BASELINE.json (16 utterances), whatever a.B is.
+    constexpr long long kNominalBatch = 16;
+    auto blocks = [&](int bm, int bn) -> long long { return (a.Mp % bm) ? -1 : (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * kNominalBatch; };
     int bm, bn, bk, nst;
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;

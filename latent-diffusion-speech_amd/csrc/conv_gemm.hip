@@ -624,9 +624,11 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 static int auto_tile(const ConvArgs& a) {
     // Prefer the 128x128 tile (2x2 MFMA tiles per wave, highest operand reuse) when it still yields
     // >= 2 workgroups per CU; otherwise fall back to smaller tiles to fill 256 CUs.
+    // judged at the nominal per-GPU batch (16 utterances): the tile fixes the reduction order, which must not depend on the
+    // batch size (per-utterance results bit-identical for any batch split)
     auto blocks = [&](int bm, int bn) -> long long {
         if (a.Mp % bm) return -1;
-        return (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B;
+        return (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * 16;
     };
     if (a.epi == EPI_GEGLU) return (blocks(128, 128) >= 384) ? 128128 : 128064;
     if (a.Mp % 64 != 0) return 32128;

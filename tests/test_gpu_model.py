@@ -107,10 +107,9 @@ def test_unit2mel_end_to_end_vs_oracle(unit2mel_gpu, monkeypatch):
 
 
 def test_batch_shard_invariance_full_size(unit2mel_gpu):
-    """BASELINE config sizes (T=512): kernels never reduce across the batch axis, so an utterance's eps does not depend on
-    its neighbours or its position: bit-identical for any placement inside equally sized batches (the weak-scaling split of
-    SURVEY.md 8e keeps the per-GPU batch size), and equal up to fp32 summation order when the batch size changes (the
-    tile shape -- hence the order of the K reduction -- is chosen from the grid size)."""
+    """BASELINE config sizes (T=512): kernels never reduce across the batch axis and the tile shapes (which fix the order of
+    every reduction) are chosen from per-utterance sizes only, so an utterance's eps is bit-identical alone, inside a batch,
+    at any position and next to any neighbours -- which is what makes the multi-GPU batch split exact."""
     from lds import init_weights
     unet = unit2mel_gpu.decoder.denoise_fn
     B, T = 4, 512
@@ -118,14 +117,13 @@ def test_batch_shard_invariance_full_size(unit2mel_gpu):
     t = dev(np.full((B,), 499.5, dtype=np.float32))
     full = unet(x, t).sample
     assert torch.isfinite(full).all()
+    one = unet(x[2:3].contiguous(), t[2:3].contiguous()).sample      # alone
+    assert torch.equal(full[2:3], one)
     perm = [2, 0, 3, 1]
-    moved = unet(x[perm].contiguous(), t).sample                     # same utterances, other positions / neighbours
+    moved = unet(x[perm].contiguous(), t).sample                     # other positions / neighbours
     assert torch.equal(full[perm], moved)
-    other = x.clone()
-    other[[0, 1, 3]] = dev(init_weights.uniform("inv.y", (3, 336, T), 32, -2, 2))
-    assert torch.equal(unet(other, t).sample[2], full[2])            # neighbours' content does not matter
-    one = unet(x[2:3].contiguous(), t[2:3].contiguous()).sample      # another batch size: same values up to rounding
-    assert float((one - full[2:3]).abs().max()) < 2e-5 * float(full.abs().max())
+    big = unet(torch.cat([x, x.flip(0), x], 0).contiguous(), torch.cat([t, t, t])).sample      # batch of 12
+    assert torch.equal(big[:B], full) and torch.equal(big[2 * B:], full)
 
 
 def test_checkpoint_formats_and_facade(tmp_path, unit2mel_gpu, monkeypatch):
