@@ -126,6 +126,21 @@ def test_batch_shard_invariance_full_size(unit2mel_gpu):
     assert torch.equal(big[:B], full) and torch.equal(big[2 * B:], full)
 
 
+@pytest.mark.parametrize("B,T", [(2, 1000), (3, 77), (40, 512), (1, 2050)])
+def test_unet_other_sizes(unit2mel_gpu, B, T):
+    """lengths that are not multiples of 8 / 64 (size=-driven upsampling, ragged tiles everywhere), long utterances and a
+    batch beyond the nominal one: finite, and utterance 0 bit-identical to its stand-alone evaluation"""
+    from lds import init_weights
+    unet = unit2mel_gpu.decoder.denoise_fn
+    x = dev(init_weights.uniform(f"sz.{B}.{T}", (B, 336, T), 33, -2, 2))
+    t = dev(np.full((B,), 250.25, dtype=np.float32))
+    full = unet(x, t).sample
+    assert full.shape == (B, 80, T) and torch.isfinite(full).all()
+    one = unet(x[:1].contiguous(), t[:1].contiguous()).sample
+    assert torch.equal(full[:1], one)
+    assert float(full.abs().max()) > 1e-3
+
+
 def test_checkpoint_formats_and_facade(tmp_path, unit2mel_gpu, monkeypatch):
     """reference on-disk formats end to end: <dir>/config.yaml + {'global_step','model'} .pt (tools/saver.py:85-109) and
     decoder.pth = {'config': h, 'model': weight-norm state_dict} (hifi_vaegan.py:6-8,57-61), loaded through
