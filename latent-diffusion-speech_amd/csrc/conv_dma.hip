@@ -211,9 +211,9 @@ struct DmaKernel {
         const int younger = (nk - 2 - kc < NST - 2) ? (nk - 2 - kc) : (NST - 2);     // tiles after kc+1 still in flight
         wait_younger<NST - 2>(younger);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kc + NST < nk && !(p.dbg & 1)) issue_tile(kc + NST, cur);
+        if (kc + NST < nk) issue_tile(kc + NST, cur);
     }
     template <int g>
     __device__ __forceinline__ void kstep(float* cur, const float* nxt, int kc, int nk) {
@@ -539,10 +539,7 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
 #define DCASE(BM, BN, KT, ST, UP, BK, NS) return launch_dma_cfg<BM, BN, KT, ST, UP, BK, NS>(a, s)
 
 // cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
-hipError_t launch_conv_dma(const DmaConvArgs& a_in, int cfg, hipStream_t s) {
-    DmaConvArgs a = a_in;
-    static const int env_dbg = getenv("LDS_DMA_DBG") ? atoi(getenv("LDS_DMA_DBG")) : 0;      // experiments only
-    a.dbg = env_dbg;
+hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || (a.pad != 0 && a.pad != 1)) return hipErrorInvalidValue;
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     static const int env_cfg = getenv("LDS_DMA_CFG") ? atoi(getenv("LDS_DMA_CFG")) : 0;     // experiments only

@@ -98,6 +98,8 @@ struct ConvKernel {
     int bcol[TN];
     f32x4 xr[XCH][4];                  // [chunk][channel row j] = 4 frames
     __amdgpu_buffer_rsrc_t rs1, rs2;   // per-batch slabs of the two sources: out-of-slab reads return 0 (hardware range check)
+    __amdgpu_buffer_rsrc_t rw;         // packed weights
+    int woffv[WCH];                    // per-lane byte offsets of this thread's weight chunks inside one K-step slab
     float cfa[4], cfb[4], cfc[4];      // per staged channel row: ROWCOEF mu, a, b ; COLSTAT gamma, beta
     f32x16 acc[NACC][TM][TN];
     f32x4 aop[NB][TM], bop[NB][TN];
@@ -158,6 +160,15 @@ struct ConvKernel {
             for (int j = 0; j < 4; ++j) xr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1 + (long long)b * p.xb1), 0, p.C1 * p.Tsrc * 4, 0x00020000);
         rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 + (long long)b * p.xb2), 0, p.C2 * p.Tsrc * 4, 0x00020000);
+        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, KT * p.Ci * p.Mp * 4, 0x00020000);
+#pragma unroll
+        for (int J = 0; J < WCH; ++J) {
+            const int q = tid + J * 256;
+            const int tap = q / (KR * BM);
+            const int rem = q - tap * (KR * BM);
+            const int rr = rem / BM, m = rem - rr * BM;
+            woffv[J] = ((tap * (p.Ci / 4) + rr) * p.Mp + m0 + m) * 16;
+        }
     }
 
     // LayerNorm over channels (reference attention.py:83,102,118): per-frame mean / rstd for this window
@@ -215,15 +226,8 @@ struct ConvKernel {
     __device__ __forceinline__ void dma_w(int kc, float* st) {
         if constexpr (J < WCH) {
             const int q0 = __builtin_amdgcn_readfirstlane(tid & ~63) + J * 256;     // first chunk of this wave
-            if (q0 < Cfg::WCHUNKS) {
-                const int q = tid + J * 256;
-                const int tap = q / (KR * BM);
-                const int rem = q - tap * (KR * BM);
-                const int rr = rem / BM, m = rem - rr * BM;
-                const float* src = p.w + ((long long)(tap * (p.Ci / 4) + kc * KR + rr) * p.Mp + m0 + m) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(st + 4 * q0), 16, 0, 0);
-            }
+            if (q0 < Cfg::WCHUNKS)      // buffer-addressed: loop-invariant per-lane offset + scalar K-step offset, no vector address math
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 4 * q0), 16, woffv[J], kc * (KR * 16) * p.Mp, 0, 0);
             dma_w<J + 1>(kc, st);
         }
     }

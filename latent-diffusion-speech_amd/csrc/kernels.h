@@ -79,7 +79,6 @@ struct DmaConvArgs {
     // mean_t / rstd_t are combined per column from the producer's partials ln_part [B][ln_np][Tsrc]
     const float2* ln_part; int ln_np; float ln_eps; const float* ln_c1; const float* ln_c2;
     int Cout, To, B;
-    int dbg;                            // experiments (LDS_DMA_DBG): 1 = no DMA in the main loop, 2 = no barrier (results are garbage)
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
