@@ -139,27 +139,19 @@ int lds_prof_enable(int on);
 int lds_prof_summary(char* buf, size_t cap);
 
 /* ---- single-op entry points (used by the parity tests to check each kernel alone) ----------- */
-typedef struct {
+typedef struct {                        /* the generic convolution (vocoder / front end path, conv_gemm)   */
     const float* x1; const float* x2;   /* dev inputs [B,C1,Tsrc], [B,C2,Tsrc] (x2 may be NULL)  */
     int C1, C2, Tsrc;
     const float* w;                     /* host, reference layout [Co, C1+C2, K]                  */
     const float* bias;                  /* host [Co] or NULL                                      */
-    int Co, K, stride, pad, dil, upsample2x;
-    int norm_mode;                      /* 0 none, 1 GroupNorm, 2 LayerNorm(over channels)        */
-    int groups; float eps;
-    const float* gamma; const float* beta;        /* host [C1+C2]                                 */
-    const float* scale_shift;           /* dev [B, 2*(C1+C2)] or NULL (resnet scale/shift)        */
-    int act_in;                         /* 0 none, 1 SiLU, 2 LeakyReLU(slope)                     */
+    int Co, K, pad, dil;
+    int act_in;                         /* 0 none, 2 LeakyReLU(slope) on the input                */
     float slope;
     const float* res;                   /* dev [B,Co,To] or NULL                                  */
-    int epilogue;                       /* 0 none, 1 GEGLU (Co = 2*out channels), 2 tanh          */
+    int epilogue;                       /* 0 none, 2 tanh                                         */
     int tile;                           /* 0 auto, else BM*1000+BN                                */
 } lds_conv_test;
 int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream);
-/* the same op launched `iters` times back to back; *ms_out = mean launch duration from HIP events on `stream` */
-int lds_bench_conv(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
-                   void* stream);
-/* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
 /* ---- the UNet's K4P path, one op at a time (plain tensors in/out; layout conversion happens on the device) ---- */
 typedef struct {
     const float* x1; const float* x2;   /* dev inputs [B,C1,T], [B,C2,T] (x2 may be NULL)                 */
@@ -169,7 +161,7 @@ typedef struct {
     const float* res;                   /* dev [B,Cout,To] or NULL                                        */
     int epilogue;                       /* 0 none, 1 GEGLU                                                */
     int plain_out;                      /* 1: the kernel writes frame-major output directly               */
-    int v_split;                        /* 1: last third of the output channels stored frame-major (QKV)  */
+    int v_split;                        /* QKV: last third of the channels frame-major (1) or in attention's VT layout with head dim v_split (> 1) */
     int cfg;                            /* 0 auto, else BM*1000000 + BN*1000 + BK*10 + NST                */
 } lds_dconv_test;
 int lds_test_dconv(const lds_dconv_test* a, float* out, float* lnpart, int B, void* stream);
@@ -179,10 +171,8 @@ int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, i
                       const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
 int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
                           float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
+/* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
 int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
-/* mid = w1*x (1x1, [C,C]); out = w2 * LayerNorm_C(mid) (1x1, [Co,C]); statistics travel as epilogue partials */
-int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
-                      float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
 int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
                             float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
                             float in_slope, void* stream);

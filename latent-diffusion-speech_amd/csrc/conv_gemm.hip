@@ -1,29 +1,18 @@
-// Implicit-GEMM 1-D convolution / 1x1-conv / linear layer for gfx950 on the exact-fp32 matrix
-// core (v_mfma_f32_32x32x2_f32).  One kernel family serves every dense contraction of the hot
-// path: reference LoRACompatibleConv / LoRACompatibleLinear / nn.Conv1d / ConvTranspose1d calls
-// (reference diffusion/unet1d/resnet.py:591-641, transformer_1d.py:256-295, attention.py:130-203,
-// encoder/hifi_vaegan/modules/models.py:185-262).
+// Generic implicit-GEMM 1-D convolution for gfx950 on the exact-fp32 matrix core (v_mfma_f32_32x32x2_f32), used where the
+// UNet's K4P / LDS-DMA kernel (conv_dma.hip) does not apply: the HiFi-VAEGAN generator (reference
+// encoder/hifi_vaegan/modules/models.py:161-262: k3/k7/k11 dilated convolutions with LeakyReLU on the input, ConvTranspose1d
+// as polyphase filters, residual / running-sum epilogues, tanh) and the unit-embedding Linear (unit2mel.py:79-82).
 //
-// Data layout: activations [B][C][T] (frames contiguous), weights re-packed once to [tap][ci][co]
-// (co contiguous) so that BOTH MFMA operands are "k-major, unit stride along the lane axis":
-//   A (weights)     lane l reads Ws[k0 + (l>>5)][m0 + (l&31)]
-//   B (activations) lane l reads Xs[k0 + (l>>5)][window(n0 + (l&31), tap)]
-// i.e. conflict-free ds_read_b32 and coalesced 16-byte global loads along the frame axis.
-// The activation window (BN*stride + halo frames of BK channels) is staged in LDS once per
-// K-step and re-read at shifted offsets by every tap (the "LDS-staged 1-D convolution window").
-// While staging, the producer's normalisation is applied on the fly (GroupNorm coefficients come
-// from a small side kernel; LayerNorm statistics are combined from per-32-channel partials that
-// the producing conv_gemm emitted in its epilogue), optionally followed by SiLU / LeakyReLU, so
-// normalised tensors are never materialised in HBM.  A second source pointer implements the
-// UNet's skip-concat on read; `ups` reads a 2x nearest-upsampled view of the source.
+// Data layout: activations plain [B][C][T] (frames contiguous), weights packed once to [tap][Ci/8][2][Mp][4] (k-interleaved,
+// output channel contiguous).  The activation window (BN frames + dilated halo of BK channels) is staged in LDS once per
+// K-step and re-read at shifted offsets by every tap; LeakyReLU is applied while staging.
 //
-// Pipeline: producer / consumer wave specialisation.  A workgroup is 8 waves: waves 4-7 (one per SIMD)
-// fetch the next tiles from global memory, apply the normalisation / activation and write the
-// double-buffered LDS stages; waves 0-3 (one per SIMD) only read LDS operands and issue MFMAs.  The
-// matrix pipe and the VALU are separate pipes of a SIMD, so the producers' address / transform work
-// runs beside the consumers' MFMA chain instead of in front of it (measured on the single-role
-// version: 37 % of wave time went to issuing VALU/LDS work, 33 % to waits, 25 % to MFMA).  One
-// LDS-only barrier per K-step; global prefetch (two tiles ahead) stays in flight across it.
+// Pipeline: producer / consumer wave specialisation.  A workgroup is 8 waves: waves 4-7 (one per SIMD) fetch the next
+// activation tile with range-checked buffer loads, apply the activation, transpose in registers and write the
+// double-buffered LDS stage, and issue the weight tile's LDS-DMA; waves 0-3 only read LDS operands (register ring, NB-1
+// groups ahead) and issue MFMAs.  One LDS-only barrier per K-step; the global prefetch stays in flight across it.  (On
+// gfx950 the producers' vector work still competes with the fp32 MFMA for issue slots -- DESIGN.md 3 -- which is why the
+// UNet moved to conv_dma; here the long reductions (K = Ci * 7..11) keep the matrix pipe at ~100 TFLOP/s.)
 #include "kernels.h"
 
 #include <math.h>
@@ -36,9 +25,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // SiLU on the staging path: hardware exp2 / rcp (about 1 ulp each); the extra ~2e-7 relative error is far inside
 // the stated 2e-5 UNet tolerance and keeps the transform at ~6 VALU ops per element
-static __device__ __forceinline__ float silu_f(float v) {
-    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));   // v_exp_f32 + v_rcp_f32
-}
 
 static __device__ __forceinline__ int floor4(int s) { return (s >= 0) ? (s & ~3) : -(((-s) + 3) & ~3); }
 
@@ -69,7 +55,7 @@ struct ConvCfg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // staging transform, resolved once per K-step so the per-element code carries no mode switches
-enum { M_PLAIN = 0, M_GN = 1, M_GN_SILU = 2, M_LN = 3, M_LRELU = 4, M_GENERIC = 5 };
+enum { M_PLAIN = 0, M_LRELU = 1 };
 
 // All per-thread state lives in one struct whose methods are force-inlined: every register array is a
 // member indexed by compile-time constants (template recursion), so nothing falls back to scratch.
@@ -92,7 +78,6 @@ struct ConvKernel {
     bool producer;
     int tid, c, h, wm, wn, b, m0, t0;
     int s_al, off, xw4, xwp, stage;
-    float* cst;
     bool vec_ok;
     int xrr, xc0, arow;
     int bcol[TN];
@@ -100,7 +85,6 @@ struct ConvKernel {
     __amdgpu_buffer_rsrc_t rs1, rs2;   // per-batch slabs of the two sources: out-of-slab reads return 0 (hardware range check)
     __amdgpu_buffer_rsrc_t rw;         // packed weights
     int woffv[WCH];                    // per-lane byte offsets of this thread's weight chunks inside one K-step slab
-    float cfa[4], cfb[4], cfc[4];      // per staged channel row: ROWCOEF mu, a, b ; COLSTAT gamma, beta
     f32x16 acc[NACC][TM][TN];
     f32x4 aop[NB][TM], bop[NB][TN];
 
@@ -134,7 +118,6 @@ struct ConvKernel {
         xw4 = (width + 3) >> 2;
         xwp = xw4 * 4;
         stage = KT * BK * BM + BK * xwp;   // floats per LDS stage
-        cst = smem + Cfg::NST * stage;     // [2][xwp] LayerNorm mean / rstd of the window's frames
         vec_ok = ((p.Tsrc & 3) == 0);
         xrr = tid / TPR;                   // staged k-row (kq*2 + h') of this thread, chunks xc0, xc0+TPR, ...
         xc0 = tid - xrr * TPR;
@@ -153,8 +136,6 @@ struct ConvKernel {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { cfa[j] = 0.f; cfb[j] = 1.f; cfc[j] = 0.f; }
-#pragma unroll
         for (int i = 0; i < XCH; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) xr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -168,34 +149,6 @@ struct ConvKernel {
             const int rem = q - tap * (KR * BM);
             const int rr = rem / BM, m = rem - rr * BM;
             woffv[J] = ((tap * (p.Ci / 4) + rr) * p.Mp + m0 + m) * 16;
-        }
-    }
-
-    // LayerNorm over channels (reference attention.py:83,102,118): per-frame mean / rstd for this window
-    __device__ __forceinline__ void colstat_prologue() {
-        for (int j = threadIdx.x; j < xwp; j += 512) {
-            const int s = s_al + j;
-            float mean = 0.f, rstd = 0.f;
-            if (s >= 0 && s < p.Tsrc) {
-                if (p.lnpart) {
-                    // Chan combination of per-32-channel (mean, M2) partials written by the producer's epilogue
-                    float n = 0.f, m2 = 0.f;
-                    for (int q = 0; q < p.ln_np; ++q) {
-                        const float2 pr = p.lnpart[((long long)b * p.ln_np + q) * p.Tsrc + s];
-                        const float d = pr.x - mean;
-                        const float nn = n + 32.f;
-                        mean += d * (32.f / nn);
-                        m2 += pr.y + d * d * (n * 32.f / nn);
-                        n = nn;
-                    }
-                    rstd = 1.0f / sqrtf(m2 / n + p.ln_eps);
-                } else {
-                    mean = p.cmean[(long long)b * p.Tsrc + s];
-                    rstd = p.crstd[(long long)b * p.Tsrc + s];
-                }
-            }
-            cst[j] = mean;
-            cst[xwp + j] = rstd;
         }
     }
 
@@ -231,28 +184,8 @@ struct ConvKernel {
             dma_w<J + 1>(kc, st);
         }
     }
-    // per-row coefficients: ALWAYS one float4 load per staged channel row (so the producers' counted vmcnt is the same
-    // in every mode): GroupNorm {mu, a, b, -} at coef[b][ci]; LayerNorm {gamma, beta, -, -} at coef[ci]; otherwise a
-    // dummy read of coef[0] (the host passes a valid pointer in every mode)
-    template <int J>
-    __device__ __forceinline__ void fetch_coef(int kc) {
-        if constexpr (J < 4) {
-            const long long idx = (p.norm_mode == NORM_ROWCOEF) ? ((long long)b * p.Ci + chan(kc, J))
-                                                               : ((p.norm_mode == NORM_COLSTAT) ? (long long)chan(kc, J) : 0ll);
-            const float4 cf = p.coef[idx];
-            cfa[J] = cf.x; cfb[J] = cf.y; cfc[J] = cf.z;
-            fetch_coef<J + 1>(kc);
-        }
-    }
     __device__ __forceinline__ void fetch(int kc) {
-        fetch_coef<0>(kc);
         fetch_x<0, 0>(kc, kc * BK >= p.C1);      // C1 % BK == 0 (checked at launch): a K-step never straddles the two sources
-    }
-
-    __device__ __forceinline__ float act(float v) const {
-        if (p.act_in == ACT_SILU) return silu_f(v);
-        if (p.act_in == ACT_LRELU) return (v >= 0.f) ? v : v * p.slope;
-        return v;
     }
 
     // piece PC of the staged tile: PC < 4*XCH -> one frame of an activation chunk (transform of 4 channel rows +
@@ -260,7 +193,6 @@ struct ConvKernel {
     // applies AFTER normalisation/activation in the reference), never branched around.
     template <int PC, int MODE>
     __device__ __forceinline__ void commit_piece(float* st) {
-        if (p.dbg & 2) return;
         if constexpr (PC < XCH * 4) {
             constexpr int I = PC / 4, E = PC % 4;
             const int c4 = xc0 + I * TPR;
@@ -271,31 +203,9 @@ struct ConvKernel {
                 if constexpr (MODE == M_PLAIN) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = xr[I][j][E];
-                } else if constexpr (MODE == M_GN) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (xr[I][j][E] - cfa[j]) * cfb[j] + cfc[j];
-                } else if constexpr (MODE == M_GN_SILU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu_f((xr[I][j][E] - cfa[j]) * cfb[j] + cfc[j]);
-                } else if constexpr (MODE == M_LN) {
-                    const float mu = cst[c4 * 4 + E], rs = cst[xwp + c4 * 4 + E];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (xr[I][j][E] - mu) * (rs * cfa[j]) + cfb[j];
-                } else if constexpr (MODE == M_LRELU) {
+                } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const float x = xr[I][j][E]; v[j] = (x >= 0.f) ? x : x * p.slope; }
-                } else {
-                    if (p.norm_mode == NORM_COLSTAT) {
-                        const float mu = cst[c4 * 4 + E], rs = cst[xwp + c4 * 4 + E];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = act((xr[I][j][E] - mu) * (rs * cfa[j]) + cfb[j]);
-                    } else if (p.norm_mode == NORM_ROWCOEF) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = act((xr[I][j][E] - cfa[j]) * cfb[j] + cfc[j]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = act(xr[I][j][E]);
-                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = inb ? v[j] : 0.f;
@@ -311,20 +221,10 @@ struct ConvKernel {
         }
     }
     __device__ __forceinline__ void commit_tile(float* st, int mode) {
-        switch (mode) {
-            case M_PLAIN: commit_range<0, P, M_PLAIN>(st); break;
-            case M_GN: commit_range<0, P, M_GN>(st); break;
-            case M_GN_SILU: commit_range<0, P, M_GN_SILU>(st); break;
-            case M_LN: commit_range<0, P, M_LN>(st); break;
-            case M_LRELU: commit_range<0, P, M_LRELU>(st); break;
-            default: commit_range<0, P, M_GENERIC>(st); break;
-        }
+        if (mode == M_PLAIN) commit_range<0, P, M_PLAIN>(st);
+        else commit_range<0, P, M_LRELU>(st);
     }
-    __device__ __forceinline__ int staging_mode() const {
-        if (p.norm_mode == NORM_NONE) return p.act_in == ACT_NONE ? M_PLAIN : (p.act_in == ACT_LRELU ? M_LRELU : M_GENERIC);
-        if (p.norm_mode == NORM_ROWCOEF) return p.act_in == ACT_NONE ? M_GN : (p.act_in == ACT_SILU ? M_GN_SILU : M_GENERIC);
-        return p.act_in == ACT_NONE ? M_LN : M_GENERIC;
-    }
+    __device__ __forceinline__ int staging_mode() const { return p.act_in == ACT_LRELU ? M_LRELU : M_PLAIN; }
 
     // MFMA operands of group (tap, kq) are read from LDS NB-1 groups ahead of their use into a small register
     // ring, so the LDS latency is covered by the MFMAs in between
@@ -342,7 +242,6 @@ struct ConvKernel {
     }
     template <int SLOT>
     __device__ __forceinline__ void mfma_ops() {
-        if (p.dbg & 4) return;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -397,7 +296,7 @@ struct ConvKernel {
     __device__ __forceinline__ void mainloop() {
         constexpr int NST = Cfg::NST;
         constexpr int AHEAD = NST - 1;                // tiles staged ahead of the one being consumed
-        constexpr int INFLIGHT = WCH + 4 + XCH * 4;   // VMEM ops of one producer iteration: weight DMA batch + coefficient/activation loads
+        constexpr int INFLIGHT = WCH + XCH * 4;   // VMEM ops of one producer iteration: weight DMA batch + activation loads
         const int nk = p.Ci / BK;
         if (producer) {
             const int mode = staging_mode();
@@ -409,7 +308,7 @@ struct ConvKernel {
                 dma_w<0>(t, smem + t * stage);
                 if (t + 1 < nk) fetch(t + 1);
             }
-            if (nk > AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XCH * 4) : "memory");   // every DMA landed, newest loads in flight
+            if (nk > AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XCH * 4) : "memory");   // every DMA landed, newest loads in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
             int sn = (AHEAD == NST) ? 0 : AHEAD;            // stage of tile kc+AHEAD
@@ -428,7 +327,7 @@ struct ConvKernel {
                             // the weight DMA issued one K-step ago must have landed; this K-step's DMA + loads stay in flight
                             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
                         } else {
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XCH * 4) : "memory");   // this K-step's DMA landed
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XCH * 4) : "memory");   // this K-step's DMA landed
                         }
                     } else {
                         if constexpr (AHEAD >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCH) : "memory");
@@ -461,9 +360,8 @@ struct ConvKernel {
     // kept OUT of the per-element loops: a branch inside them splits the loop body into basic blocks and the loads of
     // different elements can then no longer be issued together.
     template <bool PH>
-    __device__ __forceinline__ bool elem(int i, int r, int n, bool geglu, int& co, long long& oi) const {
-        const int rloc = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int orow = geglu ? (m0 + wm * 64) / 2 + rloc : m0 + wm * TM * 32 + i * 32 + rloc;
+    __device__ __forceinline__ bool elem(int i, int r, int n, int& co, long long& oi) const {
+        const int orow = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         co = orow;
         int to = n;
         if constexpr (PH) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
@@ -473,29 +371,27 @@ struct ConvKernel {
 
     // acc[0] += src[index] for every valid element of every tile: unconditional loads from a clamped index + select
     template <bool PH, bool PER_CO>
-    __device__ __forceinline__ void add_from(const float* src, bool geglu, int ni) {
+    __device__ __forceinline__ void add_from(const float* src) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (i >= ni) break;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int co; long long oi;
-                    const bool ok = elem<PH>(i, r, n, geglu, co, oi);
+                    const bool ok = elem<PH>(i, r, n, co, oi);
                     const long long idx = PER_CO ? (long long)b * p.Cout + co : oi;
                     const float v = src[ok ? idx : 0];
                     acc[0][i][j][r] += ok ? v : 0.f;
                 }
             }
-        }
     }
 
     template <bool PH>
-    __device__ __forceinline__ void epilogue_tail(bool geglu, int ni) {
-        if (p.bias_bc) add_from<PH, true>(p.bias_bc, geglu, ni);
-        if (p.res) add_from<PH, false>(p.res, geglu, ni);
+    __device__ __forceinline__ void epilogue_tail() {
+        if (p.bias_bc) add_from<PH, true>(p.bias_bc);
+        if (p.res) add_from<PH, false>(p.res);
         if (p.epi == EPI_TANH) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -504,7 +400,7 @@ struct ConvKernel {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[0][i][j][r] = tanhf(acc[0][i][j][r]);
         }
-        if (p.accum) add_from<PH, false>(p.out, geglu, ni);
+        if (p.accum) add_from<PH, false>(p.out);
         if (p.out_div != 1.0f) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -514,45 +410,22 @@ struct ConvKernel {
                     for (int r = 0; r < 16; ++r) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (i >= ni) break;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int co; long long oi;
-                    if (elem<PH>(i, r, n, geglu, co, oi)) p.out[oi] = acc[0][i][j][r];
-                }
-                if (p.lnpart_out) {
-                    // (mean, M2) of this frame over the 32 output channels of this MFMA tile: 16 values in this lane,
-                    // 16 in lane^32; combined with Chan's formula and consumed by the next layer's LayerNorm-on-load
-                    float s = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[0][i][j][r];
-                    const float m16 = s * (1.0f / 16.0f);
-                    float q = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float d = acc[0][i][j][r] - m16; q += d * d; }
-                    const float mo = __shfl_xor(m16, 32, 64), qo = __shfl_xor(q, 32, 64);
-                    const float d = mo - m16;
-                    const float mean = 0.5f * (m16 + mo);
-                    const float m2 = (q + qo) + d * d * 8.0f;
-                    const int tile32 = (m0 + wm * TM * 32 + i * 32) >> 5;
-                    if (h == 0 && n < p.To && tile32 * 32 < p.Cout)
-                        p.lnpart_out[((long long)b * (p.Cout >> 5) + tile32) * p.Tout + n] = make_float2(mean, m2);
+                    if (elem<PH>(i, r, n, co, oi)) p.out[oi] = acc[0][i][j][r];
                 }
             }
-        }
     }
 
-    // Epilogue in phases: every load of a phase (row constants; then per-element residual / broadcast bias / accumulate
-    // operands of ALL tiles) is issued before the first store.  A load placed after a store cannot be moved above it
-    // (possible aliasing -- `accum` even reads the output buffer), and a load -> wait -> store chain per element costs
-    // one memory round trip each.
+    // Epilogue in phases: every load of a phase (row bias; then per-element residual / broadcast bias / accumulate operands of
+    // ALL tiles) is issued before the first store.  A load placed after a store cannot be moved above it (possible aliasing
+    // -- `accum` even reads the output buffer), and a load -> wait -> store chain per element costs one memory round trip.
     __device__ __forceinline__ void epilogue() {
-        const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
-        const int ni = geglu ? 1 : TM;
         if constexpr (NACC == 2) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -572,17 +445,8 @@ struct ConvKernel {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[0][i][j][r] += kb[i][r];
         }
-        if (geglu) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float g = acc[0][TM - 1][j][r];
-                    acc[0][0][j][r] *= 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
-                }
-        }
-        if (p.phases > 1) epilogue_tail<true>(geglu, ni);
-        else epilogue_tail<false>(geglu, ni);
+        if (p.phases > 1) epilogue_tail<true>();
+        else epilogue_tail<false>();
     }
 };
 
@@ -591,10 +455,6 @@ __global__ void __launch_bounds__(512) conv_gemm_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ConvKernel<BM, BN, KT, STRIDE, UPS, DILMAX, BK> k(p, smem);
     k.setup();
-    if (p.norm_mode == NORM_COLSTAT) {
-        k.colstat_prologue();
-        __syncthreads();   // cst visible before the first commit
-    }
     k.mainloop();
     if (!k.producer) k.epilogue();
 }
@@ -634,9 +494,7 @@ static int auto_tile(const ConvArgs& a) {
         if (a.Mp % bm) return -1;
         return (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * 16;
     };
-    if (a.epi == EPI_GEGLU) return (blocks(128, 128) >= 384) ? 128128 : 128064;
     if (a.Mp % 64 != 0) return 32128;
-    if (a.stride == 2 || a.ups) return 64064;
     if ((a.KT == 1 || a.KT == 3) && a.dil == 1) {
         if (blocks(128, 128) >= 512) return 128128;
         if (a.Mp % 128 == 0 && blocks(128, 64) >= 512) return 128064;
@@ -649,11 +507,10 @@ static int auto_tile(const ConvArgs& a) {
 
 hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
     if (a.Ci % 16 != 0 || a.C1 % 16 != 0 || a.Mp % 32 != 0 || a.B <= 0 || a.To <= 0) return hipErrorInvalidValue;
-    if (a.lnpart_out && (a.epi != EPI_NONE || a.phases != 1 || (a.Cout & 31))) return hipErrorInvalidValue;
+    if (a.stride != 1 || a.ups || (a.epi != EPI_NONE && a.epi != EPI_TANH)) return hipErrorInvalidValue;      // conv_dma covers those for the UNet
     if (tile == 0) tile = auto_tile(a);
     const int bm = tile / 1000;
     if (a.Mp % bm != 0) return hipErrorInvalidValue;
-    if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const bool wide = a.dil > 1;
     if (a.dil > 5) return hipErrorInvalidValue;
@@ -679,10 +536,6 @@ hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
             if (key == 310 && !wide && k32) LDS_CASE(64, 64, 3, 1, false, 1, 32);
             if (key == 310 && !wide) LDS_CASE(64, 64, 3, 1, false, 1, 16);
             if (key == 310 && wide) LDS_CASE(64, 64, 3, 1, false, 5, 16);
-            if (key == 320 && k32) LDS_CASE(64, 64, 3, 2, false, 1, 32);
-            if (key == 320) LDS_CASE(64, 64, 3, 2, false, 1, 16);
-            if (key == 311 && k32) LDS_CASE(64, 64, 3, 1, true, 1, 32);
-            if (key == 311) LDS_CASE(64, 64, 3, 1, true, 1, 16);
             if (key == 710) LDS_CASE(64, 64, 7, 1, false, 5, 16);
             if (key == 1110) LDS_CASE(64, 64, 11, 1, false, 5, 16);
             break;

@@ -12,8 +12,7 @@ namespace lds {
 // via per-(b,t) statistics) followed by an optional activation; out-of-range taps read exact zeros.
 // The MFMA is v_mfma_f32_32x32x2_f32 (exact fp32); A = packed weights (M = co), B = activations (N = t).
 // ---------------------------------------------------------------------------------------------
-enum { NORM_NONE = 0, NORM_ROWCOEF = 1, NORM_COLSTAT = 2 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
+enum { ACT_NONE = 0, ACT_LRELU = 2 };      // activation applied to the input while staging (conv_gemm)
 enum { EPI_NONE = 0, EPI_GEGLU = 1, EPI_TANH = 2 };
 
 struct ConvArgs {
@@ -26,29 +25,20 @@ struct ConvArgs {
     // packed weights [KT][Ci][Mp]
     const float* w;
     int Mp, Co, Ci, KT, stride, dil, pad, ups;
-    // normalise-on-load
-    int norm_mode;
-    const float4* coef;      // NORM_ROWCOEF: [B][Ci] {mu, a, b, -}: v = (x-mu)*a + b; NORM_COLSTAT: [Ci] {gamma, beta, -, -};
-                             // NORM_NONE: any valid device pointer (read, ignored)
-    const float* cmean; const float* crstd;   // NORM_COLSTAT: [B][Tsrc]
-    const float2* lnpart; int ln_np; float ln_eps;   // NORM_COLSTAT alternative to cmean/crstd: [B][ln_np][Tsrc] (mean, M2)
-                                                     // partials over 32 channels each, combined in the kernel prologue
     int act_in; float slope;
     // epilogue
-    const float* bias;       // [Co] (for GEGLU: packed order, Mp entries) or null
+    const float* bias;       // [Mp] packed-row bias or null
     const float* bias_bc;    // [B][Co] extra per-(batch,channel) bias or null
     const float* res;        // [B][Cout][To] residual or null
     int epi;
     int accum;               // 1: out = (out + y) / out_div  (MRF running sum), 0: out = y / out_div
     float out_div;           // 1.0 normally
     float* out;
-    float2* lnpart_out;      // optional [B][Cout/32][Tout]: per-frame (mean, M2) over each 32-channel group of the output
-    int Cout;                // channels of `out` (Co, or Co/2 for GEGLU, or Co/phases for transposed conv)
+    int Cout;                // channels of `out` (Co, or Co/phases for transposed conv)
     int To;                  // columns computed (N)
     // transposed-conv scatter: row m = co*phases + phi -> out[b][co][n*phases + phi - tpad] (phases=1: plain)
     int phases, tpad, Tout;  // Tout = row length of out
     int B;
-    int dbg;                 // diagnostics only (tools/bench_conv.py, LDS_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA
 };
 
 // tile: 0 = auto, else BM*1000+BN in {128128, 64064, 128064, 64128, 32128}
@@ -104,17 +94,6 @@ hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Ti
 // self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v in the VT layout
 // [B][heads][ceil(T/4)][D][4] (key tail zeroed); out K4P [B][C][T]
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s);
-
-// ---------------------------------------------------------------------------------------------
-// Normalisation statistics
-// ---------------------------------------------------------------------------------------------
-// GroupNorm over the virtual concat [x1;x2] -> coef[b][ci] = {mean_g, rstd_g*gamma*(1+scale), beta*(1+scale)+shift, 0}
-hipError_t launch_gn_coef(const float* x1, const float* x2, int C1, int C2, int T, long long xb1, long long xb2,
-                          int groups, float eps, const float* gamma, const float* beta,
-                          const float* scale_shift /*[B][ss_stride] scale at +ss_off, shift at +ss_off+C or null*/,
-                          int ss_stride, int ss_off, float4* coef, int B, hipStream_t s);
-// LayerNorm statistics over channels: mean[b][t], rstd[b][t]
-hipError_t launch_ln_stats(const float* x, int C, int T, float eps, float* mean, float* rstd, int B, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small dense layers with N = batch columns (time embedding path)

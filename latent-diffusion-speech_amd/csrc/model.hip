@@ -263,9 +263,6 @@ struct Src {
 };
 struct ConvOpt {
     int stride = 1, pad = 0, dil = 1, ups = 0;
-    int norm_mode = NORM_NONE; const float4* coef = nullptr;
-    const float* cmean = nullptr; const float* crstd = nullptr;
-    const float2* lnpart = nullptr; int ln_np = 0; float ln_eps = 1e-5f; float2* lnpart_out = nullptr;
     int act_in = ACT_NONE; float slope = 0.f;
     const float* bias_bc = nullptr; const float* res = nullptr;
     int epi = EPI_NONE; int accum = 0; float out_div = 1.f;
@@ -281,8 +278,6 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.xb1 = (long long)s.C1 * s.Tsrc; a.xb2 = (long long)s.C2 * s.Tsrc;
     a.w = W.w; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
     a.stride = o.stride; a.dil = o.dil; a.pad = o.pad; a.ups = o.ups;
-    a.norm_mode = o.norm_mode; a.coef = o.coef ? o.coef : (const float4*)W.w; a.cmean = o.cmean; a.crstd = o.crstd;
-    a.lnpart = o.lnpart; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.lnpart_out = o.lnpart_out;
     a.act_in = o.act_in; a.slope = o.slope;
     a.bias = W.bias; a.bias_bc = o.bias_bc; a.res = o.res; a.epi = o.epi; a.accum = o.accum; a.out_div = o.out_div;
     a.out = out;
@@ -291,10 +286,9 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.To = o.To > 0 ? o.To : To_nat;
     a.Tout = o.Tout > 0 ? o.Tout : a.To;
     a.phases = o.phases; a.tpad = o.tpad;
-    a.Cout = o.Cout > 0 ? o.Cout : (o.epi == EPI_GEGLU ? W.Co / 2 : W.Co / o.phases);
+    a.Cout = o.Cout > 0 ? o.Cout : W.Co / o.phases;
     a.B = B;
-    { static const char* d = getenv("LDS_DBG"); a.dbg = d ? atoi(d) : 0; }
-    const double real_rows = (o.epi == EPI_GEGLU || o.phases > 1) ? (double)W.Co : (double)(a.Cout);
+    const double real_rows = (o.phases > 1) ? (double)W.Co : (double)(a.Cout);
     const double flops = 2.0 * B * (double)a.To * real_rows * (double)W.Ci * (double)W.K;
     const double bytes = 4.0 * ((double)B * W.Ci * s.Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.Tout * (o.res ? 2.0 : 1.0));
     hipError_t e;
@@ -1210,80 +1204,21 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
 // ================================================================================================
 // Single-op test entry points
 // ================================================================================================
-static int test_conv_impl(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, void* stream) {
+extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream) {
     if (!a || !out) return fail(LDS_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     Owner own;
     ConvW W;
     const int Ci = a->C1 + a->C2;
-    bool ok;
-    if (a->epilogue == EPI_GEGLU) ok = pack_geglu(own, a->w, a->bias, a->Co, Ci, W);
-    else ok = pack_conv(own, a->w, a->bias, a->Co, Ci, a->K, W);
-    if (!ok) return fail(LDS_ENOMEM, "test conv: upload failed");
-    const int T = a->Tsrc;
-    void* tmp = nullptr;
-    const size_t coef_b = (size_t)B * Ci * sizeof(float4), st_b = (size_t)B * T * sizeof(float);
-    HIP_TRY(hipMalloc(&tmp, coef_b + 2 * st_b + 1024));
-    own.ptrs.push_back(tmp);
-    float4* coef = (float4*)tmp;
-    float* lm = (float*)((char*)tmp + coef_b);
-    float* lr = lm + (size_t)B * T;
-    float *g = nullptr, *be = nullptr;
-    if (a->norm_mode) {
-        g = up_vec(own, a->gamma, Ci);
-        be = up_vec(own, a->beta, Ci);
-        if (!g || !be) return fail(LDS_ENOMEM, "test conv: upload failed");
-    }
+    if (!pack_conv(own, a->w, a->bias, a->Co, Ci, a->K, W)) return fail(LDS_ENOMEM, "test conv: upload failed");
     ConvOpt o;
-    o.stride = a->stride; o.pad = a->pad; o.dil = a->dil; o.ups = a->upsample2x;
+    o.pad = a->pad; o.dil = a->dil;
     o.act_in = a->act_in; o.slope = a->slope; o.res = a->res; o.epi = a->epilogue; o.tile = a->tile;
-    if (a->norm_mode == NORM_ROWCOEF) {
-        HIP_TRY(launch_gn_coef(a->x1, a->x2 ? a->x2 : a->x1, a->C1, a->C2, T, (long long)a->C1 * T, (long long)a->C2 * T, a->groups, a->eps,
-                               g, be, a->scale_shift, 2 * Ci, 0, coef, B, st));
-        o.norm_mode = NORM_ROWCOEF; o.coef = coef;
-    } else if (a->norm_mode == NORM_COLSTAT) {
-        if (a->C2) return fail(LDS_EINVAL, "LayerNorm test takes a single source");
-        HIP_TRY(launch_ln_stats(a->x1, Ci, T, a->eps, lm, lr, B, st));
-        std::vector<float> gb((size_t)4 * Ci, 0.f);
-        for (int c = 0; c < Ci; ++c) { gb[4 * c] = a->gamma[c]; gb[4 * c + 1] = a->beta[c]; }
-        float4* dgb = (float4*)own.upload(gb);
-        if (!dgb) return fail(LDS_ENOMEM, "test conv: upload failed");
-        o.norm_mode = NORM_COLSTAT; o.cmean = lm; o.crstd = lr; o.coef = dgb;
-    }
-    Src s{a->x1, a->C1, a->x2, a->C2, T};
-    int r = run_conv(W, s, o, out, B, st);
-    if (r == LDS_OK && iters > 0 && ms_out) {
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, st));
-        for (int i = 0; i < iters && r == LDS_OK; ++i) r = run_conv(W, s, o, out, B, st);
-        HIP_TRY(hipEventRecord(e1, st));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        *ms_out = ms / iters;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-    }
+    Src s{a->x1, a->C1, a->x2, a->C2, a->Tsrc};
+    const int r = run_conv(W, s, o, out, B, st);
     HIP_TRY(hipStreamSynchronize(st));   // test-only entry point: temporaries are freed on return
     return r;
 }
-
-extern "C" int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream) {
-    if (!a || !out) return fail(LDS_EINVAL, "bad argument");
-    return test_conv_impl(a, out, B, 0, nullptr, stream);
-}
-
-// same op launched `iters` times back to back (weights packed once); *ms_out = average kernel time from HIP events
-extern "C" int lds_bench_conv(const lds_conv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
-                              void* stream) {
-    if (!a || !out || !ms_out || iters <= 0) return fail(LDS_EINVAL, "bad argument");
-    int r = test_conv_impl(a, out, B, iters, ms_out, stream);
-    if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_gemm_last_config());
-    return r;
-}
-
 
 // ---- K4P path test entry points: plain tensors in / out, converted on the device ----
 struct TmpDev {
@@ -1445,32 +1380,6 @@ extern "C" int lds_test_attention_k4p(const float* qkv, float* out, int B, int C
     HIP_TRY(launch_from_k4p(ko, out, B, C, T, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
-}
-
-// conv1 (1x1, emits LayerNorm partials) -> conv2 (1x1, LayerNorm-on-load from those partials)
-extern "C" int lds_test_ln_chain(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
-                                 float* mid, float* out, int B, int C, int Co, int T, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    Owner own;
-    ConvW W1, W2;
-    if (!pack_conv(own, w1, nullptr, C, C, 1, W1) || !pack_conv(own, w2, nullptr, Co, C, 1, W2)) return fail(LDS_ENOMEM, "upload failed");
-    std::vector<float> gbv((size_t)4 * C, 0.f);
-    for (int c = 0; c < C; ++c) { gbv[4 * c] = gamma[c]; gbv[4 * c + 1] = beta[c]; }
-    float4* dgb = (float4*)own.upload(gbv);
-    if (!dgb) return fail(LDS_ENOMEM, "upload failed");
-    void* part = nullptr;
-    HIP_TRY(hipMalloc(&part, (size_t)B * (C / 32) * T * sizeof(float2)));
-    own.ptrs.push_back(part);
-    Src s1{x, C, nullptr, 0, T};
-    ConvOpt o1;
-    o1.lnpart_out = (float2*)part;
-    LDS_TRY(run_conv(W1, s1, o1, mid, B, st));
-    Src s2{mid, C, nullptr, 0, T};
-    ConvOpt o2;
-    o2.norm_mode = NORM_COLSTAT; o2.lnpart = (const float2*)part; o2.ln_np = C / 32; o2.ln_eps = eps; o2.coef = dgb;
-    int r = run_conv(W2, s2, o2, out, B, st);
-    HIP_TRY(hipStreamSynchronize(st));
-    return r;
 }
 
 extern "C" int lds_test_conv_transpose(const float* x, const float* w, const float* bias, float* out, int B, int Ci, int Co, int T, int K,

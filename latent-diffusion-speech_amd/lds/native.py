@@ -28,11 +28,8 @@ class VocoderCfg(C.Structure):
 
 class ConvTest(C.Structure):
     _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("C1", C.c_int), ("C2", C.c_int), ("Tsrc", C.c_int),
-                ("w", C.c_void_p), ("bias", C.c_void_p), ("Co", C.c_int), ("K", C.c_int), ("stride", C.c_int),
-                ("pad", C.c_int), ("dil", C.c_int), ("upsample2x", C.c_int), ("norm_mode", C.c_int),
-                ("groups", C.c_int), ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("scale_shift", C.c_void_p), ("act_in", C.c_int), ("slope", C.c_float), ("res", C.c_void_p),
-                ("epilogue", C.c_int), ("tile", C.c_int)]
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("Co", C.c_int), ("K", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
+                ("act_in", C.c_int), ("slope", C.c_float), ("res", C.c_void_p), ("epilogue", C.c_int), ("tile", C.c_int)]
 
 
 class DConvTest(C.Structure):
@@ -46,7 +43,7 @@ EXPORTS = [
     "lds_last_error", "lds_version", "lds_unet_create", "lds_unet_destroy", "lds_unet_workspace_bytes",
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
-    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_bench_conv", "lds_test_ln_chain", "lds_test_dconv", "lds_bench_dconv",
+    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
     "lds_test_gn_apply", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
     "lds_test_conv_transpose"]
 
