@@ -8,7 +8,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NDMA, int NLDS, bool BAR>
+template <int NDMA, int NLDS, bool BAR, bool SPREAD = false>
 __global__ void __launch_bounds__(256) feed(const float* __restrict__ src, long long win_floats, int iters, float* out, long long* clk, int share) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 stages x 32 KB
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -23,8 +23,8 @@ __global__ void __launch_bounds__(256) feed(const float* __restrict__ src, long 
     f32x4 a = {1.f, 2.f, 3.f, 4.f}, b = {0.5f, 0.25f, 0.125f, 1.f};
     long long off = 0;
     for (int it = 0; it < iters; ++it) {
-        float* st = smem + (it & 1) * 8192;
-        if (NDMA) {
+        float* st = smem + (SPREAD ? it % 3 : (it & 1)) * 8192;      // SPREAD: 3 stages, the one read was filled two steps ago
+        if (NDMA && !SPREAD) {
 #pragma unroll
             for (int d = 0; d < NDMA; ++d) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((d < NDMA / 2 ? baseW : baseX) + off + ((wave * NDMA + d) * 64 + lane) * 4),
@@ -34,10 +34,18 @@ __global__ void __launch_bounds__(256) feed(const float* __restrict__ src, long 
             if (off + 4 * NDMA * 256 > win_floats) off = 0;
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");       // the previous step's loads have landed
         }
-        if (BAR) __builtin_amdgcn_s_barrier();
-        const float* rd = smem + ((it + 1) & 1) * 8192;
+        if (BAR && !SPREAD) __builtin_amdgcn_s_barrier();
+        const float* rd = smem + (SPREAD ? (it + 1) % 3 : ((it + 1) & 1)) * 8192;
+        if (NDMA && SPREAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (SPREAD && BAR) __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
+            if (SPREAD && g < NDMA) {
+                if (g == 0) { off += 4 * NDMA * 256; if (off + 4 * NDMA * 256 > win_floats) off = 0; }     // one DMA per MFMA group instead of a burst at the top of the step
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((g < NDMA / 2 ? baseW : baseX) + off + ((wave * NDMA + g) * 64 + lane) * 4),
+                                                 (__attribute__((address_space(3))) void*)(st + ((wave * NDMA + g) * 64) * 4), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (NLDS) {
                 if (g * 2 < NLDS) a = *reinterpret_cast<const f32x4*>(rd + (g * 256 + lane) * 4);
                 if (g * 2 + 1 < NLDS) b = *reinterpret_cast<const f32x4*>(rd + (g * 256 + 64 + lane) * 4 + 2048 * (wave & 1));
@@ -56,16 +64,16 @@ __global__ void __launch_bounds__(256) feed(const float* __restrict__ src, long 
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
-template <int NDMA, int NLDS, bool BAR>
+template <int NDMA, int NLDS, bool BAR, bool SPREAD = false>
 void run(const char* name, const float* src, long long win, int occ, float* out, long long* clk, int share = 0) {
     const int iters = 4000, grid = 256 * occ;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(feed<NDMA, NLDS, BAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const size_t lds = 65536;      // 2 workgroups per CU at most, like conv_dma's BK64 tile
+    hipFuncSetAttribute(reinterpret_cast<const void*>(feed<NDMA, NLDS, BAR, SPREAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = SPREAD ? 98304 : 65536;      // 2 workgroups per CU at most, like conv_dma's BK64 tile (1 for the 3-stage variant)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((feed<NDMA, NLDS, BAR>), dim3(grid), dim3(256), lds, 0, src, win, iters, out, clk, share);
+    hipLaunchKernelGGL((feed<NDMA, NLDS, BAR, SPREAD>), dim3(grid), dim3(256), lds, 0, src, win, iters, out, clk, share);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((feed<NDMA, NLDS, BAR>), dim3(grid), dim3(256), lds, 0, src, win, iters, out, clk, share);
+    hipLaunchKernelGGL((feed<NDMA, NLDS, BAR, SPREAD>), dim3(grid), dim3(256), lds, 0, src, win, iters, out, clk, share);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -96,6 +104,8 @@ int main() {
             run<8, 16, true>("... 16 ds_read + 8 DMA + barrier, shared", src, win, occ, out, clk, 1);
             run<4, 16, true>("... 16 ds_read + 4 DMA + barrier, shared", src, win, occ, out, clk, 1);
             run<8, 16, true>("... 8 DMA, shared, half the rows 16 B misaligned", src, win, occ, out, clk, 3);
+            run<8, 16, true, true>("... 16 ds_read + 8 DMA + barrier, DMA spread", src, win, occ, out, clk, 1);
+            run<4, 16, true, true>("... 16 ds_read + 4 DMA + barrier, DMA spread", src, win, occ, out, clk, 1);
         }
     }
     return 0;
