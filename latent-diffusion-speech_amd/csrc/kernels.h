@@ -7,9 +7,8 @@
 namespace lds {
 
 // ---------------------------------------------------------------------------------------------
-// conv_gemm: out[b,co,t] = epi( bias[co] + sum_{tap,ci} Wp[tap][ci][co] * f(X[b,ci, t*stride + tap*dil - pad]) )
-// f = optional normalise-on-load (GroupNorm via per-(b,ci) coefficients, or LayerNorm over channels
-// via per-(b,t) statistics) followed by an optional activation; out-of-range taps read exact zeros.
+// conv_gemm (vocoder / front end): out[b,co,t] = epi( bias[co] + sum_{tap,ci} Wp[tap][ci][co] * f(X[b,ci, t + tap*dil - pad]) )
+// f = optional LeakyReLU applied while staging; out-of-range taps read exact zeros.
 // The MFMA is v_mfma_f32_32x32x2_f32 (exact fp32); A = packed weights (M = co), B = activations (N = t).
 // ---------------------------------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_LRELU = 2 };      // activation applied to the input while staging (conv_gemm)

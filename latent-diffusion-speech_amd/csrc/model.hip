@@ -708,7 +708,8 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
 
 static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st) {
     // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major (K4P).  Every conv that feeds a
-    // LayerNorm also emits per-32-channel (mean, M2) partials per frame; ln_apply combines them.
+    // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer (QKV / FF1) combines them per column and
+    // applies the LayerNorm in its epilogue (weights pre-multiplied by gamma, pack_ln_fold).
     const int C = t.C;
     HIP_TRY(launch_gn_apply(x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.part, w.gno, B, st));
     DOpt op;
