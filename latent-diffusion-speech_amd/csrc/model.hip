@@ -742,8 +742,29 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
 
 // uniform_t: every batch element shares t[0] (the samplers' case) -> the time-embedding path runs for one column and
 // the resnets read it with batch stride 0
+// time embedding for n timesteps t[0..n): e1 / emb are [n][temb] scratch, tproj [n][tp_M] receives every resnet's projection
+static int time_embedding(const lds_unet* u, const float* t, float* e1, float* emb, float* tproj, int n, hipStream_t st) {
+    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, e1, u->temb, 1, u->temb, u->tproj_dim, n, st));
+    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, e1, u->temb, IN_PLAIN, nullptr, emb, u->temb, 1, u->temb, u->temb, n, st));
+    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, emb, u->temb, IN_PLAIN, nullptr, tproj, u->tp_M, 0, u->tp_M, u->temb, n, st));
+    return LDS_OK;
+}
+
+// the condition is the same for every evaluation of a sampler run: its channels of the K4P input tensor are written once
+static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_bytes, int B, int T, hipStream_t st) {
+    Arena A(ws, ws_bytes);
+    UnetWs w;
+    plan_ws(u, A, B, T, w);
+    if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
+    HIP_TRY(launch_to_k4p(cond, w.xin, B, u->H, T, u->M + u->H, u->M, st));
+    return LDS_OK;
+}
+
+// tproj_pre: this timestep's column of all resnets' time_emb_proj outputs, computed ahead by the sampler (implies uniform_t);
+// cond_staged: the condition channels of the input tensor were already converted by unet_stage_cond
 static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
-                             int B, int T, hipStream_t st, bool uniform_t = false) {
+                             int B, int T, hipStream_t st, bool uniform_t = false, const float* tproj_pre = nullptr,
+                             bool cond_staged = false) {
     Arena A(ws, ws_bytes);
     UnetWs w;
     plan_ws(u, A, B, T, w);
@@ -753,14 +774,16 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     // e1 = SiLU(linear_1(sinusoid(t))); emb = SiLU(linear_2(e1)) -- every consumer of emb applies SiLU first
     // (resnet.py:610), so only the activated embedding is stored
     const int Bt = uniform_t ? 1 : B;
-    w.ss_stride = uniform_t ? 0 : u->tp_M;
-    HIP_TRY(launch_small_linear(u->t_w1, u->t_b1, t, 1, IN_SINUSOID, u->freqs, w.e1, u->temb, 1, u->temb, u->tproj_dim, Bt, st));
-    HIP_TRY(launch_small_linear(u->t_w2, u->t_b2, w.e1, u->temb, IN_PLAIN, nullptr, w.emb, u->temb, 1, u->temb, u->temb, Bt, st));
-    HIP_TRY(launch_small_linear(u->tp_w, u->tp_b, w.emb, u->temb, IN_PLAIN, nullptr, w.tproj, u->tp_M, 0, u->tp_M, u->temb, Bt, st));
+    w.ss_stride = (uniform_t || tproj_pre) ? 0 : u->tp_M;
+    if (tproj_pre) {
+        w.tproj = const_cast<float*>(tproj_pre);
+    } else {
+        LDS_TRY(time_embedding(u, t, w.e1, w.emb, w.tproj, Bt, st));
+    }
     // the virtual concat [x ; cond] (reference diffusion.py:105) becomes one K4P tensor
     const int cin = u->M + u->H;
     HIP_TRY(launch_to_k4p(x, w.xin, B, u->M, T, cin, 0, st));
-    HIP_TRY(launch_to_k4p(cond, w.xin, B, u->H, T, cin, u->M, st));
+    if (!cond_staged) HIP_TRY(launch_to_k4p(cond, w.xin, B, u->H, T, cin, u->M, st));
     size_t si = 0;
     {
         DOpt o;
@@ -844,12 +867,15 @@ extern "C" int lds_unet_forward(lds_unet* u, const float* x, const float* cond, 
 // ================================================================================================
 // Sampler loops
 // ================================================================================================
-struct SampWs { float *tvec, *eps, *m0, *m1, *m2, *xt, *xp; size_t unet_off; };
+constexpr int kTimePre = 64;      // timesteps whose embeddings are computed ahead per sampler call (a DDPM chunk is 64 rows)
+struct SampWs { float *tvec, *eps, *m0, *m1, *m2, *xt, *xp, *tp_t, *tp_e1, *tp_emb, *tp_proj; size_t unet_off; };
 
 static void plan_samp(const lds_unet* u, Arena& A, int B, int T, SampWs& s) {
     const size_t n = (size_t)B * u->M * T;
     s.tvec = A.f(B);
     s.eps = A.f(n); s.m0 = A.f(n); s.m1 = A.f(n); s.m2 = A.f(n); s.xt = A.f(n); s.xp = A.f(n);
+    s.tp_t = A.f(kTimePre); s.tp_e1 = A.f((size_t)kTimePre * u->temb); s.tp_emb = A.f((size_t)kTimePre * u->temb);
+    s.tp_proj = A.f((size_t)kTimePre * u->tp_M);
     s.unet_off = A.used;
 }
 
@@ -877,9 +903,26 @@ extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float*
     const size_t uws_bytes = ws_bytes - s.unet_off;
     const long long n = (long long)B * u->M * T;
     const int S = LDS_TABLE_STRIDE;
+    // Every evaluation of a run shares the condition and uses a timestep known from the table: the condition channels are
+    // converted once, and the time embeddings (time MLP + all 22 time_emb_proj, 75 MB of weights) of all steps are computed
+    // in one batched pass instead of once per evaluation.  Per-column results do not depend on the batching.
+    std::vector<float> tlist;
+    for (int i = 0; i < n_rows; ++i) tlist.push_back(table[(size_t)i * S]);
+    if (method == LDS_METHOD_PLMS) tlist.push_back(table[1]);
+    const bool pre = (int)tlist.size() <= kTimePre;
+    if (pre) {
+        HIP_TRY(hipMemcpyAsync(s.tp_t, tlist.data(), tlist.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        LDS_TRY(time_embedding(u, s.tp_t, s.tp_e1, s.tp_emb, s.tp_proj, (int)tlist.size(), st));
+    }
+    LDS_TRY(unet_stage_cond(u, cond, uws, uws_bytes, B, T, st));
     auto model = [&](const float* xin, float t_in) -> int {
+        if (pre) {
+            for (size_t i = 0; i < tlist.size(); ++i)
+                if (tlist[i] == t_in)
+                    return unet_forward_impl(u, xin, cond, nullptr, s.eps, uws, uws_bytes, B, T, st, true, s.tp_proj + i * u->tp_M, true);
+        }
         HIP_TRY(launch_fill(s.tvec, t_in, B, st));
-        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st, true);
+        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st, true, nullptr, true);
     };
     float *m0 = s.m0, *m1 = s.m1, *m2 = s.m2;
     if (method == LDS_METHOD_DPM_SOLVER_PP) {
