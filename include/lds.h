@@ -80,7 +80,8 @@ int lds_unet_forward(lds_unet* u, const float* x, const float* cond, const float
 
 /* `table` (host, n_rows x LDS_TABLE_STRIDE floats) holds the per-step scalar coefficients,
  * computed by the caller from the noise schedule in fp32 (layout per method: see
- * latent-diffusion-speech_amd/diffusion/diffusion.py and csrc/sampler.hip).
+ * latent-diffusion-speech_amd/diffusion/diffusion.py and lds_sampler_run in csrc/model.hip).  The table is read on the
+ * host during the call (it may be freed afterwards); no device synchronisation is performed.
  * x dev [B,M,T] is x_T on entry and the sample on return; cond dev [B,H,T];
  * noise dev [n_rows,B,M,T] for DDPM (one draw per step), else NULL. */
 int lds_sampler_run(lds_unet* u, int method, int n_rows, const float* table, const float* cond,
