@@ -553,9 +553,10 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
     int bm, bn, bk, nst;
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
-    } else if (a.stride == 1 && !a.ups && a.epi != EPI_GEGLU && k32 && blocks(64, 64) <= 256) {
+    } else if (a.stride == 1 && !a.ups && a.epi != EPI_GEGLU && k32 && (blocks(64, 64) <= 256 || (blocks(64, 64) < 512 && blocks(64, 64) % 256))) {
         // fewer 64 x 64 tiles than CUs (the T/8 and T/4 levels at small batch): 32 x 64 tiles with the K range split over the
-        // workgroup's two wave pairs put twice as many CUs to work (tools/bench_dconv.py: 1.6x at 128 tiles, ~1.1x at 256)
+        // workgroup's two wave pairs put twice as many CUs to work (tools/bench_dconv.py: 1.6x at 128 tiles, ~1.1x at 256);
+        // 1.5 tiles per CU (384: the T/2 level) leave half the chip idle in the second round, 3 half tiles per CU do not (1.2x)
         bm = 32; bn = 64; bk = (a.KT == 1 && k64) ? 64 : 32; nst = 2;
     } else {
         // Pick the tile by a small occupancy model fitted to tools/bench_dconv.py sweeps: a CU runs its n workgroups r at a
