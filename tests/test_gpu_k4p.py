@@ -157,12 +157,13 @@ def test_conv_dma_value_layout(C, heads, T):
     assert (vt.transpose(0, 1, 3, 2, 4).reshape(B, C, T4)[:, :, T:] == 0).all()
 
 
-def test_conv_dma_layernorm_partials():
-    """the epilogue's per-frame (mean, M2) over each 32-channel tile"""
+@pytest.mark.parametrize("cfg", [0, 64064322, 32064322])
+def test_conv_dma_layernorm_partials(cfg):
+    """the epilogue's per-frame (mean, M2) over each 32-channel tile (also from the split-K tile)"""
     B, C, T = 2, 128, 70
     x = U("lnp.x", (B, 64, T), -2, 2)
     w = U("lnp.w", (C, 64, 1)) / np.float32(8.0)
-    out, ln = run_dconv(x, w, want_ln=True)
+    out, ln = run_dconv(x, w, want_ln=True, cfg=cfg)
     t = out.reshape(B, C // 32, 32, T).astype(np.float64)
     assert np.abs(ln[..., 0] - t.mean(2)).max() < 1e-5
     assert np.abs(ln[..., 1] - ((t - t.mean(2, keepdims=True)) ** 2).sum(2)).max() < 1e-3
