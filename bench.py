@@ -129,7 +129,7 @@ def main():
     def step():
         mel = model(units, None, spk_id=spk, infer=True, infer_speedup=speedup, method=args.method)
         wav = voc(mel) if voc is not None else None
-        out = shard.gather_batch(mel, rank, world)
+        out = shard.gather_batch(mel, rank, world, sizes=[B] * world)
         return out, wav
 
     def barrier():

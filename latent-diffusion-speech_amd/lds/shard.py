@@ -30,12 +30,14 @@ def scatter_batch(full, rank, world, src=0):
     return buf[lo:hi].contiguous()
 
 
-def gather_batch(local, rank, world, dst=0):
-    """Concatenate per-rank results [n_r, ...] on rank `dst` (equal n_r -> all_gather_into_tensor)."""
+def gather_batch(local, rank, world, dst=0, sizes=None):
+    """Concatenate per-rank results [n_r, ...] on rank `dst` (equal n_r -> all_gather_into_tensor).
+    `sizes` = the per-rank n_r when the caller knows them (saves the object collective and its host synchronisation)."""
     if world == 1:
         return local
-    sizes = [None] * world
-    dist.all_gather_object(sizes, int(local.shape[0]))
+    if sizes is None:
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(local.shape[0]))
     if len(set(sizes)) == 1:
         out = torch.empty((sum(sizes),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
