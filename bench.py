@@ -113,8 +113,8 @@ def main():
         spk_all = torch.from_numpy((np.arange(world * B) * 37 % 323 + 1).astype(np.float32)).to(dev)
     else:
         units_all, spk_all = torch.empty(0, device=dev), torch.empty(0, device=dev)
-    units = shard.scatter_batch(units_all, rank, world)
-    spk = shard.scatter_batch(spk_all.reshape(-1, 1), rank, world).to(torch.int64) if world > 1 else spk_all.reshape(-1, 1).to(torch.int64)
+    units = shard.scatter_batch(units_all, rank, world, shape=(world * B, T, 1280))
+    spk = shard.scatter_batch(spk_all.reshape(-1, 1), rank, world, shape=(world * B, 1)).to(torch.int64)
     del units_all
     gen = torch.Generator(device=dev)
     gen.manual_seed(2 + rank)

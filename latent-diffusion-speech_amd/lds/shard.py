@@ -15,15 +15,18 @@ def shard_range(n_items, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def scatter_batch(full, rank, world, src=0):
+def scatter_batch(full, rank, world, src=0, shape=None):
     """Rank `src` holds `full` [N, ...]; every rank returns its shard [n_r, ...].
     One broadcast of the batch (RCCL broadcast over xGMI on the GPU box) + a local slice: the same code path for
-    even and ragged splits, and only collectives every backend implements."""
+    even and ragged splits, and only collectives every backend implements.  `shape` = the full shape when every rank
+    knows it (saves the object broadcast)."""
     if world == 1:
         return full
-    shape = [tuple(full.shape) if rank == src else None]
-    dist.broadcast_object_list(shape, src=src)
-    shp = shape[0]
+    if shape is None:
+        box = [tuple(full.shape) if rank == src else None]
+        dist.broadcast_object_list(box, src=src)
+        shape = box[0]
+    shp = tuple(shape)
     buf = full.contiguous() if rank == src else torch.empty(shp, dtype=torch.float32, device=full.device)
     dist.broadcast(buf, src=src)
     lo, hi = shard_range(shp[0], rank, world)
