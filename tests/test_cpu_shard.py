@@ -38,10 +38,16 @@ def _worker(rank, world, port, n_items, q):
         ref = torch.arange(n_items * 6, dtype=torch.float32).reshape(n_items, 2, 3)[lo:hi]
         ok = torch.equal(mine, ref)
         out = shard.gather_batch(mine * 2.0, rank, world)        # per-utterance work, then gather on rank 0
+        # the same with the shapes known up front (bench.py's path: no object collectives)
+        mine2 = shard.scatter_batch(full, rank, world, shape=(n_items, 2, 3))
+        sizes = [shard.shard_range(n_items, r, world)[1] - shard.shard_range(n_items, r, world)[0] for r in range(world)]
+        out2 = shard.gather_batch(mine2 * 2.0, rank, world, sizes=sizes)
+        ok2 = torch.equal(mine2, ref) and ((out2 is None) if rank else torch.equal(out2, out))
         if rank == 0:
             ok = ok and torch.equal(out, torch.arange(n_items * 6, dtype=torch.float32).reshape(n_items, 2, 3) * 2.0)
         else:
             ok = ok and out is None
+        ok = ok and ok2
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
