@@ -170,6 +170,10 @@ int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int iters, float
                     void* stream);
 int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                       const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
+/* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
+ * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
+int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,
+                          int groups, int silu, float* mid, float* out, int B, int C, int Co, int T, int cfg, void* stream);
 int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
                           float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
 /* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */

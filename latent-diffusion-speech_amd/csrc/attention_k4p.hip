@@ -250,11 +250,10 @@ template <int D, int NW, int NST, int KS>
 static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, hipStream_t s) {
     using Cfg = AttCfg<D, NW, NST, KS>;
     auto kern = attention_k4p_kernel<D, NW, NST, KS>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (Cfg::LDS_BYTES > 48 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     constexpr int QPB = NW / KS * 32;       // queries per workgroup
     hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);

@@ -46,6 +46,21 @@ static __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(fmaf(-pl * t, e, 1.0f), x);
 }
 
+// Wave64 sum in a fixed order (DPP row shifts + row broadcasts, no LDS): the total is valid in lane 63.
+template <int CTRL, int ROW_MASK, bool BOUND>
+static __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+static __device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0x111, 0xf, true>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf, true>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf, true>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf, true>(v);      // row_shr:8   lane 15 of every 16-lane row = the row's sum
+    v = dpp_add<0x142, 0xa, false>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc, false>(v);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
 struct DmaCfg {
     // BM = 32: split-K inside the workgroup for grids smaller than the chip.  The tile is 32 x 64; waves (wn, ks) take
@@ -433,6 +448,33 @@ struct DmaKernel {
                 for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 + 4) = f32x2{0.f, 0.f};
             }
         }
+        if (p.gnpart_out) {
+            // GroupNorm statistics of the tensor being written, for the consumer's streaming normalisation (k4p_ops.hip
+            // gn_stream): per (16 channels x 32 frames) block one (mean, M2) over its valid frames.  Registers 0..7 of a
+            // lane are channels tile0 + 0..15, registers 8..15 channels tile0 + 16..31; sums of (x - k) and (x - k)^2 with
+            // k = the block's first element (a shift near the mean keeps the sum-of-squares form free of cancellation),
+            // reduced over the wave in a fixed order.
+            const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][i][j][0])));
+            const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][i][j][8])));
+            float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float d0 = acc[0][i][j][r] - k0, d1 = acc[0][i][j][r + 8] - k1;
+                a1 += d0; a2 = fmaf(d0, d0, a2);
+                b1 += d1; b2 = fmaf(d1, d1, b2);
+            }
+            if (!ok) { a1 = 0.f; a2 = 0.f; b1 = 0.f; b2 = 0.f; }
+            a1 = wave_sum_to_lane63(a1); a2 = wave_sum_to_lane63(a2);
+            b1 = wave_sum_to_lane63(b1); b2 = wave_sum_to_lane63(b2);
+            const int n0 = n - c;                                   // first frame of this 32-frame block
+            const int nv = (p.To - n0 < 32) ? p.To - n0 : 32;       // valid frames
+            if (lane == 63 && nv > 0) {
+                const float cnt = 16.0f * (float)nv, rc = 1.0f / cnt;
+                float2* gp = p.gnpart_out + ((long long)b * (Ck >> 4) + (tile0 >> 4)) * ((p.To + 31) >> 5) + (n0 >> 5);
+                gp[0] = make_float2(k0 + a1 * rc, fmaxf(a2 - a1 * a1 * rc, 0.f));
+                if (tile0 + 16 < Ck) gp[(p.To + 31) >> 5] = make_float2(k1 + b1 * rc, fmaxf(b2 - b1 * b1 * rc, 0.f));
+            }
+        }
         if (p.lnpart_out) {
             // per-frame (mean, M2) over this tile's 32 channels -> LayerNorm partials (combined by the consumer, ln_columns)
             float s1 = 0.f;
@@ -524,11 +566,10 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
     const int nN = (a.To + BN - 1) / BN;
     dim3 grid((a.Mp / BM) * nN, a.B);
     auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (Cfg::LDS_BYTES > 48 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x,
              grid.y, Cfg::LDS_BYTES);
@@ -542,8 +583,6 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || (a.pad != 0 && a.pad != 1)) return hipErrorInvalidValue;
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
-    static const int env_cfg = getenv("LDS_DMA_CFG") ? atoi(getenv("LDS_DMA_CFG")) : 0;     // experiments only
-    if (cfg == 0) cfg = env_cfg;
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     // The tile shape fixes the order of the K reduction, so it must not depend on the batch size: an utterance's result is then
     // bit-identical for any batch split.  Grid sizes are therefore judged at the nominal per-GPU batch of

@@ -474,11 +474,10 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int nN = (a.To + BN - 1) / BN;
     dim3 grid((a.Mp / BM) * nN, a.B);
     auto kern = conv_gemm_kernel<BM, BN, KT, STRIDE, UPS, DILMAX, BK>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 48 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     snprintf(g_cfg, sizeof(g_cfg), "BM%d BN%d KT%d S%d U%d BK%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, grid.x, grid.y, lds);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
@@ -514,9 +513,8 @@ hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s) {
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const bool wide = a.dil > 1;
     if (a.dil > 5) return hipErrorInvalidValue;
-    static const int bk_max = getenv("LDS_BK") ? atoi(getenv("LDS_BK")) : 64;    // experiments only
-    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0) && bk_max >= 32;
-    const bool k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0) && bk_max >= 64;
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0);
+    const bool k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     switch (tile) {
         case 128128:
             if (key == 110 && k32) LDS_CASE(128, 128, 1, 1, false, 1, 32);

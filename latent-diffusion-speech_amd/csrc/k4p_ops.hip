@@ -2,8 +2,8 @@
 // GroupNorm(+scale/shift)(+SiLU) and LayerNorm materialised ONCE per tensor (reference nn.GroupNorm / SiLU in
 // resnet.py:591-641, transformer_1d.py:134,262; nn.LayerNorm in attention.py:83,102,118), nearest resampling.
 // An 8-channel block of a K4P tensor is one contiguous run of 2*(T+2)*4 floats, so all of these stream 16-byte
-// entries with unit stride; the GroupNorm statistics are per-block partials (one workgroup per block) combined
-// with Chan's formula, never atomics, so results do not depend on scheduling.
+// entries with unit stride; the GroupNorm statistics are per-block partials written by the producing convolution's
+// epilogue and combined with Chan's formula in a fixed order, never atomics, so results do not depend on scheduling.
 #include "k4p.h"
 #include "kernels.h"
 
@@ -13,23 +13,6 @@
 namespace lds {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-static __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <int NT>
-static __device__ __forceinline__ float bsum(float v, float* red) {
-    v = wsum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < NT / 64; ++i) t += red[i];
-    return t;
-}
 
 // one workgroup per (b, 8-channel block)
 __global__ void __launch_bounds__(256) to_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int Ctot, int c_off) {
@@ -85,209 +68,189 @@ hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, 
     return hipGetLastError();
 }
 
-// ---- GroupNorm: pass 1, per 8-channel block (mean, M2) over its 8*T real elements.  One read: sums of (x - k) and
-//      (x - k)^2 with k = the block's first element (a shift close to the mean removes the cancellation of the naive
-//      sum / sum-of-squares form); blocks are combined in pass 2 with Chan's formula ----
-__global__ void __launch_bounds__(256) gn_part_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
-                                                      float4* __restrict__ part) {
-    __shared__ float red[4];
-    const int q = blockIdx.x, b = blockIdx.y;
-    const int Tp = T + 2, nq1 = C1 >> 3;
-    const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
-    const float k = xb[4];                     // element (h=0, t=0, j=0)
-    float s1 = 0.f, s2 = 0.f;
-    for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
-        const int hh = idx / T, t = idx - hh * T;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = v[j] - k; s1 += d; s2 += d * d; }
-    }
-    s1 = bsum<256>(s1, red);
-    s2 = bsum<256>(s2, red);
-    const float n = 8.0f * (float)T;
-    if (threadIdx.x == 0) part[(long long)b * ((C1 + C2) >> 3) + q] = make_float4(k + s1 / n, fmaxf(s2 - s1 * s1 / n, 0.f), n, 0.f);
+// ---- GroupNorm -------------------------------------------------------------------------------------------------
+// Statistics travel as (mean, M2) partials of (16 channels x 32 frames) blocks, [B][C/16][ceil(T/32)] float2.  conv_dma
+// writes them from its epilogue for every tensor that feeds a GroupNorm (DmaConvArgs::gnpart_out); gn_partials_kernel
+// computes the same from a K4P tensor (stand-alone entry points).  gn_stream_kernel is the only pass over the tensor.
+
+// Wave64 reduction helpers in a fixed order (DPP row shifts + row broadcasts): the result is valid in lane 63.
+template <int CTRL, int ROW_MASK, bool BOUND>
+static __device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+static __device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += dpp_get<0x111, 0xf, true>(v);
+    v += dpp_get<0x112, 0xf, true>(v);
+    v += dpp_get<0x114, 0xf, true>(v);
+    v += dpp_get<0x118, 0xf, true>(v);
+    v += dpp_get<0x142, 0xa, false>(v);
+    v += dpp_get<0x143, 0xc, false>(v);
+    return v;
+}
+// Chan's parallel combination of (count, mean, M2); an empty side (count 0) is the identity
+static __device__ __forceinline__ void chan(float& n, float& mean, float& m2, float nb, float mb, float qb) {
+    const float nn = n + nb;
+    const float r = (nn > 0.f) ? 1.0f / nn : 0.f;
+    const float d = mb - mean;
+    mean += d * (nb * r);
+    m2 += qb + d * d * (n * nb * r);
+    n = nn;
+}
+template <int CTRL, int ROW_MASK, bool BOUND>
+static __device__ __forceinline__ void chan_step(float& n, float& mean, float& m2) {
+    // lanes outside ROW_MASK (and row starts with BOUND) receive zeros = an empty partial
+    const float nb = dpp_get<CTRL, ROW_MASK, BOUND>(n), mb = dpp_get<CTRL, ROW_MASK, BOUND>(mean), qb = dpp_get<CTRL, ROW_MASK, BOUND>(m2);
+    chan(n, mean, m2, nb, mb, qb);
 }
 
-// ---- GroupNorm: pass 2, combine the group's block partials, normalise + affine (+scale/shift) (+SiLU), write K4P ----
-__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
-                                                       int groups, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ ss, int ss_stride, int ss_off, int silu,
-                                                       const float4* __restrict__ part, float* __restrict__ y) {
-    const int q = blockIdx.x, b = blockIdx.y;
+// one wave per (16-channel block, 32-frame block)
+__global__ void __launch_bounds__(64) gn_partials_kernel(const float* __restrict__ x, int C, int T, float2* __restrict__ gp) {
+    const int nT = (T + 31) >> 5, kb = blockIdx.x / nT, tb = blockIdx.x - kb * nT, b = blockIdx.y, lane = threadIdx.x;
+    const int Tp = T + 2;
+    const float* xb = x + (((long long)b * (C >> 3) + 2 * kb) * 2) * Tp * 4;      // 4 rows: (q = 2kb, 2kb+1) x (hh = 0, 1)
+    const int t = tb * 32 + (lane & 31), half = lane >> 5;                          // each lane: two rows of one frame
+    const bool ok = t < T;
+    const float k = xb[(long long)(tb * 32 + 1) * 4];                               // element (row 0, first frame of the block, j = 0)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = half * 2 + rr;
+        f32x4 v = {k, k, k, k};
+        if (ok) v = *reinterpret_cast<const f32x4*>(xb + ((long long)row * Tp + t + 1) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[j] - k; s1 += d; s2 = fmaf(d, d, s2); }
+    }
+    s1 = wave_sum_to_lane63(s1);
+    s2 = wave_sum_to_lane63(s2);
+    const int nv = (T - tb * 32 < 32) ? T - tb * 32 : 32;
+    if (lane == 63) {
+        const float cnt = 16.0f * (float)nv, rc = 1.0f / cnt;
+        gp[((long long)b * (C >> 4) + kb) * nT + tb] = make_float2(k + s1 * rc, fmaxf(s2 - s1 * s1 * rc, 0.f));
+    }
+}
+hipError_t launch_gn_partials(const float* x, int C, int T, float2* gp, int B, hipStream_t s) {
+    if (C & 15) return hipErrorInvalidValue;
+    ProfScope ps(s, "gn_partials", 0.0, 4.0 * B * (double)C * T);
+    hipLaunchKernelGGL(gn_partials_kernel, dim3((C / 16) * ((T + 31) / 32), B), dim3(64), 0, s, x, C, T, gp);
+    return hipGetLastError();
+}
+
+// One workgroup per (batch, 8-channel block): E x 256 entries of 16 bytes are requested first, the group's statistics are
+// combined from the partials while those loads are in flight (every wave does it redundantly: no LDS, no barrier), then
+// normalise + affine (+scale/shift) (+SiLU) and store; the pad frames are written as zeros.
+template <int E>
+__global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
+                                                        int groups, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ ss, int ss_stride, int ss_off, int silu,
+                                                        const float2* __restrict__ gp1, const float2* __restrict__ gp2, float* __restrict__ y) {
+    const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
-    const int bpg = nq / groups;                     // 8-channel blocks per group
-    const int g0 = (q / bpg) * bpg;
-    float mean = 0.f, m2 = 0.f, n = 0.f;
-    for (int i0 = 0; i0 < bpg; i0 += 8) {            // Chan's parallel combination, fixed order; partials fetched 8 at a time
-        float4 pp[8];
+    const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
+    float* yb = y + (((long long)b * nq + q) * 2) * Tp * 4;
+    const int total = 2 * T;                          // real entries of this block: (row hh, frame t) -> idx = hh * T + t
+    // ---- 1. request the first chunk ----
+    f32x4 v[E];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pp[e] = part[(long long)b * nq + g0 + ((i0 + e < bpg) ? i0 + e : i0)];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (i0 + e < bpg) {
-                const float d = pp[e].x - mean, nn = n + pp[e].z;
-                mean += d * (pp[e].z / nn);
-                m2 += pp[e].y + d * d * (n * pp[e].z / nn);
-                n = nn;
-            }
+    for (int i = 0; i < E; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < total) {
+            const int hh = idx >= T, t = idx - hh * T;
+            v[i] = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
         }
     }
-    const float rstd = 1.0f / sqrtf(m2 / n + eps);
-    // per-channel coefficients of this block: v = (x - mean) * a + bb
-    float a[2][4], bb[2][4];
+    // ---- 2. per-channel affine terms ----
+    float ga[2][4], be[2][4];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ci = q * 8 + 2 * j + hh;
-            float aa = rstd * gamma[ci], be = beta[ci];
+            float g_ = gamma[ci], b_ = beta[ci];
             if (ss) {
                 const float sc = 1.0f + ss[(long long)b * ss_stride + ss_off + ci];
                 const float sh = ss[(long long)b * ss_stride + ss_off + C + ci];
-                aa *= sc;
-                be = be * sc + sh;
+                g_ *= sc;
+                b_ = b_ * sc + sh;
             }
-            a[hh][j] = aa; bb[hh][j] = be;
+            ga[hh][j] = g_; be[hh][j] = b_;
         }
-    const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
-    float* yb = y + (((long long)b * nq + q) * 2) * Tp * 4;
-    for (int idx = threadIdx.x; idx < 2 * Tp; idx += 256) {
-        const int hh = idx / Tp, e = idx - hh * Tp;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (e >= 1 && e <= T) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long long)idx * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float r = (xv[j] - mean) * a[hh][j] + bb[hh][j];
-                if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                v[j] = r;
-            }
+    // ---- 3. group statistics from the partials ----
+    const int cg16 = (C / groups) >> 4;               // 16-channel blocks per group
+    const int g = (q * 8) / (C / groups);
+    const int nT = (T + 31) >> 5, P = cg16 * nT, nk1 = C1 >> 4;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int p0 = 0; p0 < P; p0 += 64) {              // <= 2 rounds for every shape of the UNet
+        const int pi = p0 + lane;
+        float nb = 0.f, mb = 0.f, qb = 0.f;
+        if (pi < P) {
+            const int kk = pi / nT, tb = pi - kk * nT, kb = g * cg16 + kk;
+            const float2 pr = (kb < nk1) ? gp1[((long long)b * nk1 + kb) * nT + tb] : gp2[((long long)b * (C2 >> 4) + (kb - nk1)) * nT + tb];
+            const int nv = (T - tb * 32 < 32) ? T - tb * 32 : 32;
+            nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
         }
-        *reinterpret_cast<f32x4*>(yb + (long long)idx * 4) = v;      // pad frames written as zeros
+        chan(n, mean, m2, nb, mb, qb);
     }
-}
-
-// ---- GroupNorm in ONE pass over memory: one 1024-thread workgroup per (batch, group) keeps the whole group
-//      ((C/groups) channels x T frames, <= MAXI 16-byte entries per thread) in registers: exact two-pass statistics
-//      (mean, then sum of squared deviations) from the registers, then normalise + affine (+scale/shift) (+SiLU) and
-//      write.  All of a thread's loads are issued before the first use.  Sums are combined in a fixed order. ----
-template <int MAXI>
-__global__ void __launch_bounds__(1024) gn_fused_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
-                                                        int groups, float eps, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const float* __restrict__ ss, int ss_stride,
-                                                        int ss_off, int silu, float* __restrict__ y) {
-    constexpr int NT = 1024, MAXR = 64;
-    __shared__ float red[NT / 64];
-    __shared__ __attribute__((aligned(16))) float cA[MAXR * 4], cB[MAXR * 4];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
-    const int bpg = nq / groups, R = 2 * bpg;      // rows (block, hh) of Tp entries each
-    const int dq = NT / Tp, dr = NT - dq * Tp;
-    // per-channel affine terms of row tid>>2, element tid&3 (fetched early; finished once the statistics are known)
-    float ga = 0.f, be = 0.f, sc = 1.f, sh = 0.f;
-    if (tid < R * 4) {
-        const int row = tid >> 2, ci = (g * bpg + (row >> 1)) * 8 + 2 * (tid & 3) + (row & 1);
-        ga = gamma[ci]; be = beta[ci];
-        if (ss) {
-            sc = 1.0f + ss[(long long)b * ss_stride + ss_off + ci];
-            sh = ss[(long long)b * ss_stride + ss_off + C + ci];
-        }
+    chan_step<0x111, 0xf, true>(n, mean, m2);
+    chan_step<0x112, 0xf, true>(n, mean, m2);
+    chan_step<0x114, 0xf, true>(n, mean, m2);
+    chan_step<0x118, 0xf, true>(n, mean, m2);
+    chan_step<0x142, 0xa, false>(n, mean, m2);
+    chan_step<0x143, 0xc, false>(n, mean, m2);
+    const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mean), 63));
+    const float var = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m2), 63)) /
+                      __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n), 63));
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[hh][j] *= rstd;
+    // ---- 4. normalise and store ----
+    if (tid < 4) {                                    // the four pad entries (frames -1 and T of both rows)
+        const int hh = tid >> 1, e = (tid & 1) ? T + 1 : 0;
+        *reinterpret_cast<f32x4*>(yb + ((long long)hh * Tp + e) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    f32x4 v[MAXI];
-    {
-        int row = tid / Tp, e = tid - row * Tp;
+    for (int base = 0; base < total; base += 256 * E) {
+        if (base > 0) {
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < R && e >= 1 && e <= T) {
-                const int q = g * bpg + (row >> 1);
-                const float* src = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2 + (row & 1)) * Tp * 4
-                                             : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2 + (row & 1)) * Tp * 4;
-                v[i] = *reinterpret_cast<const f32x4*>(src + (long long)e * 4);
-            }
-            row += dq; e += dr;
-            if (e >= Tp) { e -= Tp; ++row; }
-        }
-    }
-    const float n = (float)(C / groups) * (float)T;
-    float s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);      // pad / idle entries hold zeros
-    const float mean = bsum<NT>(s1, red) / n;
-    float s2 = 0.f;
-    {
-        int row = tid / Tp, e = tid - row * Tp;
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            if (row < R && e >= 1 && e <= T) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
-            }
-            row += dq; e += dr;
-            if (e >= Tp) { e -= Tp; ++row; }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(bsum<NT>(s2, red) / n + eps);
-    if (tid < R * 4) {
-        const float aa = rstd * ga * sc;
-        cA[tid] = aa;
-        cB[tid] = be * sc + sh;
-    }
-    __syncthreads();
-    float* yb = y + ((long long)b * nq + (long long)g * bpg) * 2 * Tp * 4;      // the group's rows are contiguous in the output
-    {
-        int row = tid / Tp, e = tid - row * Tp, idx = tid;
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            if (row < R) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};                              // pad frames written as zeros
-                if (e >= 1 && e <= T) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(cA + row * 4), b4 = *reinterpret_cast<const f32x4*>(cB + row * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float r = (v[i][j] - mean) * a4[j] + b4[j];
-                        if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                        o[j] = r;
-                    }
+            for (int i = 0; i < E; ++i) {
+                const int idx = base + tid + 256 * i;
+                if (idx < total) {
+                    const int hh = idx >= T, t = idx - hh * T;
+                    v[i] = *reinterpret_cast<const f32x4*>(xb + ((long long)hh * Tp + t + 1) * 4);
                 }
-                *reinterpret_cast<f32x4*>(yb + (long long)idx * 4) = o;
             }
-            row += dq; e += dr; idx += NT;
-            if (e >= Tp) { e -= Tp; ++row; }
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int idx = base + tid + 256 * i;
+            if (idx < total) {
+                const int hh = idx >= T, t = idx - hh * T;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float r = (v[i][j] - mu) * (hh ? ga[1][j] : ga[0][j]) + (hh ? be[1][j] : be[0][j]);
+                    if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
+                    o[j] = r;
+                }
+                *reinterpret_cast<f32x4*>(yb + ((long long)hh * Tp + t + 1) * 4) = o;
+            }
         }
     }
 }
 
-template <int MAXI>
-static hipError_t launch_gn_fused(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
-                                  const float* beta, const float* ss, int ss_stride, int ss_off, int silu, float* y, int B, hipStream_t s) {
-    hipLaunchKernelGGL(gn_fused_kernel<MAXI>, dim3(groups, B), dim3(1024), 0, s, x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss,
-                       ss_stride, ss_off, silu, y);
-    return hipGetLastError();
-}
-
-hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
-                           const float* beta, const float* ss, int ss_stride, int ss_off, int silu, float4* part, float* y, int B,
-                           hipStream_t s) {
+hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                            const float* beta, const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2,
+                            float* y, int B, hipStream_t s) {
     const int C = C1 + C2;
-    if ((C1 & 7) || (C2 & 7) || (C / 8) % groups) return hipErrorInvalidValue;
-    static const bool two_kernels = getenv("LDS_GN_SPLIT") != nullptr;      // experiments only
-    const long long entries = (long long)(C / 8 / groups) * 2 * (T + 2);
-    const int need = (int)((entries + 1023) / 1024);
-    if (!two_kernels && need <= 12 && 2 * (C / 8 / groups) <= 64) {          // the group fits one workgroup's registers
-        ProfScope ps(s, "gn_fused", 0.0, 4.0 * 2.0 * B * (double)C * T);
-        if (need <= 2) return launch_gn_fused<2>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
-        if (need <= 4) return launch_gn_fused<4>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
-        if (need <= 9) return launch_gn_fused<9>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
-        return launch_gn_fused<12>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, y, B, s);
-    }
-    {
-        ProfScope ps(s, "gn_part", 0.0, 4.0 * 2.0 * B * (double)C * T);
-        hipLaunchKernelGGL(gn_part_kernel, dim3(C / 8, B), dim3(256), 0, s, x1, x2 ? x2 : x1, C1, C2, T, part);
-    }
-    ProfScope ps(s, "gn_apply", 0.0, 4.0 * 2.0 * B * (double)C * T);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(C / 8, B), dim3(256), 0, s, x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride,
-                       ss_off, silu, part, y);
+    if ((C1 & 15) || (C2 & 15) || groups <= 0 || C % groups || (C / groups) % 16 || !gp1 || (C2 && !gp2)) return hipErrorInvalidValue;
+    ProfScope ps(s, "gn_stream", 0.0, 4.0 * 2.0 * B * (double)C * T);
+    const dim3 grid(C / 8, B), blk(256);
+    const int need = (2 * T + 255) / 256;
+#define GN_ARGS x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2 ? gp2 : gp1, y
+    if (need <= 1) hipLaunchKernelGGL(gn_stream_kernel<1>, grid, blk, 0, s, GN_ARGS);
+    else if (need <= 2) hipLaunchKernelGGL(gn_stream_kernel<2>, grid, blk, 0, s, GN_ARGS);
+    else hipLaunchKernelGGL(gn_stream_kernel<4>, grid, blk, 0, s, GN_ARGS);
+#undef GN_ARGS
     return hipGetLastError();
 }
 

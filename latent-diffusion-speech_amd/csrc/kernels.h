@@ -4,6 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <string>
+
 namespace lds {
 
 // ---------------------------------------------------------------------------------------------
@@ -63,6 +66,7 @@ struct DmaConvArgs {
     int plain_from; float* out2;        // output channels >= plain_from go frame-major to out2 [B][Cout-plain_from][To] ...
     int vt_D;                           // ... or, when vt_D > 0, in attention's VT layout [B][(Cout-plain_from)/vt_D][ceil(To/4)][vt_D][4]
     float2* lnpart_out;                 // optional [B][C/32][To] per-frame (mean, M2) partials over 32-channel tiles
+    float2* gnpart_out;                 // optional [B][C/16][ceil(To/32)] (mean, M2) of every (16 channels x 32 frames) block of the K4P output (GroupNorm statistics for gn_stream)
     // LayerNorm of the INPUT folded into the epilogue (weights pre-multiplied by gamma on the host):
     //   y[m,t] = rstd_t * (acc[m,t] - mean_t * ln_c1[m]) + ln_c2[m],  c1 = sum_c W[m,c]*gamma_c,  c2 = sum_c W[m,c]*beta_c + bias[m]
     // mean_t / rstd_t are combined per column from the producer's partials ln_part [B][ln_np][Tsrc]
@@ -84,10 +88,15 @@ hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hip
 hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, int D, hipStream_t s);
 // GroupNorm of the virtual concat [x1;x2] (K4P) -> y (K4P, C1+C2 channels):
 //   y = act(((x - mean_g) * rstd_g * gamma + beta) * (1 + scale) + shift), act = SiLU if silu
-// `part` is scratch for [B][(C1+C2)/8] float4 partial statistics.
-hipError_t launch_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps,
-                           const float* gamma, const float* beta, const float* scale_shift, int ss_stride, int ss_off,
-                           int silu, float4* part, float* y, int B, hipStream_t s);
+// One streaming pass (1 read + 1 write, one workgroup per (batch, 8-channel block)): the group statistics come from
+// the per-(16 channels x 32 frames) (mean, M2) partials gp1 / gp2 [B][C/16][ceil(T/32)] that the producers of x1 / x2
+// wrote in their epilogues (DmaConvArgs::gnpart_out) and are combined per workgroup with Chan's formula in a fixed order
+// while the tensor loads are in flight.
+hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps,
+                            const float* gamma, const float* beta, const float* scale_shift, int ss_stride, int ss_off,
+                            int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s);
+// the same partials computed from a K4P tensor by a stand-alone pass (tensors not produced by conv_dma; test entry points)
+hipError_t launch_gn_partials(const float* x, int C, int T, float2* gp, int B, hipStream_t s);
 // nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
 hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
 // self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v in the VT layout
@@ -133,8 +142,22 @@ hipError_t launch_resample_nearest(const float* in, float* out, int B, int C, in
 struct ProfScope {
     bool on;
     hipStream_t s;
+    int idx = -1;
     ProfScope(hipStream_t st, const char* name, double flops, double bytes);
     ~ProfScope();
+    void rename(const std::string& n);
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize must be raised once per (kernel, device); `done` is that kernel's per-device bit mask
+inline hipError_t ensure_max_dynamic_lds(const void* kern, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      // idempotent: a concurrent second call is harmless
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 }  // namespace lds

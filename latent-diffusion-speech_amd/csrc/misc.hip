@@ -151,10 +151,12 @@ hipError_t launch_transpose(const float* in, float* out, int B, int R, int C, fl
 __global__ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, int idx_off,
                                    float* __restrict__ out, int C, int nrows) {
     const int b = blockIdx.x;
-    long long r = idx[b] + idx_off;
-    if (r < 0) r = 0;
-    if (r >= nrows) r = nrows - 1;
-    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) out[(long long)b * C + cc] = table[r * C + cc];
+    // An index outside the table (nn.Embedding raises for it, reference unit2mel.py:82) poisons the row with NaN, so the
+    // error surfaces in the output instead of silently selecting another speaker; host-side ids are range-checked before
+    // the call (Unit2Mel.forward)
+    const long long r = idx[b] + idx_off;
+    const bool ok = r >= 0 && r < nrows;
+    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) out[(long long)b * C + cc] = ok ? table[r * C + cc] : __builtin_nanf("");
 }
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, int idx_off, float* out, int B, int C, int nrows, hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, s, table, idx, idx_off, out, C, nrows);

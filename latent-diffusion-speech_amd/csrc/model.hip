@@ -11,7 +11,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,50 +51,74 @@ extern "C" int lds_version(void) { return 1; }
 // boundary event (a kernel's stop is the next kernel's start): an interval is that kernel's execution plus its own dispatch,
 // not two event packets per kernel.
 struct ProfRec { std::string name; double flops, bytes; int ia, ib; };
-static bool g_prof_on = false, g_prof_chain = false;
+// level 0 = off, 1 = one record per kernel family / tile configuration, 2 = names also carry the operand shapes.
+// The records are process-global and guarded by g_prof_mu; with the profiler off (the product path) a launch only reads
+// the atomic level, so forward calls on different streams / threads share no mutable state (include/lds.h conventions).
+static std::atomic<int> g_prof_level{0};
+static std::mutex g_prof_mu;
+static bool g_prof_chain = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_ev;
 static hipStream_t g_prof_last_stream = nullptr;
 static int g_prof_last_stop = -1;
 
-static int prof_mark(hipStream_t st) {
+static int prof_mark(hipStream_t st) {      // g_prof_mu held
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return -1;
     (void)hipEventRecord(e, st);
     g_prof_ev.push_back(e);
     return (int)g_prof_ev.size() - 1;
 }
-lds::ProfScope::ProfScope(hipStream_t st, const char* name, double flops, double bytes) : on(g_prof_on), s(st) {
+lds::ProfScope::ProfScope(hipStream_t st, const char* name, double flops, double bytes) : on(g_prof_level.load(std::memory_order_relaxed) != 0), s(st) {
     if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.name = name; r.flops = flops; r.bytes = bytes; r.ib = -1;
     r.ia = (g_prof_chain && g_prof_last_stop >= 0 && g_prof_last_stream == st) ? g_prof_last_stop : prof_mark(st);
     if (r.ia < 0) { on = false; return; }
     g_prof.push_back(r);
+    idx = (int)g_prof.size() - 1;
 }
 lds::ProfScope::~ProfScope() {
     if (!on) return;
-    g_prof.back().ib = prof_mark(s);
-    g_prof_last_stop = g_prof.back().ib;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx < 0 || idx >= (int)g_prof.size()) return;      // the profiler was reset while this scope was open
+    g_prof[idx].ib = prof_mark(s);
+    g_prof_last_stop = g_prof[idx].ib;
     g_prof_last_stream = s;
 }
+void lds::ProfScope::rename(const std::string& n) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx >= 0 && idx < (int)g_prof.size()) g_prof[idx].name = n;
+}
 struct ProfChain {      // RAII: boundary events are shared while alive
-    bool prev;
-    ProfChain() : prev(g_prof_chain) { g_prof_chain = true; g_prof_last_stop = -1; }
-    ~ProfChain() { g_prof_chain = prev; g_prof_last_stop = -1; }
+    bool prev = false, act;
+    ProfChain() : act(g_prof_level.load(std::memory_order_relaxed) != 0) {
+        if (!act) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        prev = g_prof_chain; g_prof_chain = true; g_prof_last_stop = -1;
+    }
+    ~ProfChain() {
+        if (!act) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_chain = prev; g_prof_last_stop = -1;
+    }
 };
 
 extern "C" int lds_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
     g_prof_ev.clear();
     g_prof.clear();
     g_prof_last_stop = -1;
-    g_prof_on = on != 0;
+    g_prof_level.store(on < 0 ? 0 : (on > 2 ? 2 : on));
     return LDS_OK;
 }
 
 // JSON: [{"name":..., "count":n, "ms":total, "flops":total, "bytes":total}, ...]; synchronises the recorded events.
 extern "C" int lds_prof_summary(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     struct Agg { long long n = 0; double ms = 0, fl = 0, by = 0; };
     std::map<std::string, Agg> agg;
     for (auto& r : g_prof) {
@@ -295,17 +321,15 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     {
         ProfScope ps(st, "conv_gemm", flops, bytes);
         e = launch_conv_gemm(a, o.tile, st);
-    }
-    if (g_prof_on && !g_prof.empty() && g_prof.back().name == "conv_gemm") {
-        const char* c = conv_gemm_last_config();   // "BM.. BN.. KT.. S.. U.. grid ..."
-        std::string cfgs(c);
-        size_t p = cfgs.find(" grid");
-        g_prof.back().name = "conv_gemm<" + cfgs.substr(0, p) + ">";
-        static const bool shapes = getenv("LDS_PROF_SHAPES") != nullptr;      // per-shape breakdown for tuning sessions
-        if (shapes) {
-            char sh[96];
-            snprintf(sh, sizeof(sh), " Ci%d Co%d K%d d%d To%d%s%s", W.Ci, W.Co, W.K, o.dil, a.To, o.phases > 1 ? " convT" : "", o.res ? " +res" : "");
-            g_prof.back().name += sh;
+        if (ps.on) {
+            std::string cfgs(conv_gemm_last_config());   // "BM.. BN.. KT.. S.. U.. grid ..."
+            std::string nm = "conv_gemm<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            if (g_prof_level.load(std::memory_order_relaxed) >= 2) {      // per-shape breakdown (bench.py's vocoder leg, tuning sessions)
+                char sh[96];
+                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d d%d To%d%s%s", W.Ci, W.Co, W.K, o.dil, a.To, o.phases > 1 ? " convT" : "", o.res ? " +res" : "");
+                nm += sh;
+            }
+            ps.rename(nm);
         }
     }
     if (e != hipSuccess)
@@ -322,6 +346,7 @@ struct DOpt {
     float* out2 = nullptr;
     int vt_D = 0;
     float2* lnpart_out = nullptr;
+    float2* gnpart_out = nullptr;
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
 };
@@ -336,7 +361,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     a.res = o.res; a.epi = o.epi; a.out = out; a.out_plain = o.out_plain;
     a.Cout = (o.epi == EPI_GEGLU) ? W.Co / 2 : W.Co;
     a.plain_from = (o.plain_from >= 0) ? o.plain_from : a.Cout;
-    a.out2 = o.out2; a.vt_D = o.vt_D; a.lnpart_out = o.lnpart_out;
+    a.out2 = o.out2; a.vt_D = o.vt_D; a.lnpart_out = o.lnpart_out; a.gnpart_out = o.gnpart_out;
     a.ln_part = o.ln_part; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.ln_c1 = o.ln_c1; a.ln_c2 = o.ln_c2;
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
     a.To = (Tin + 2 * o.pad - (W.K - 1) - 1) / o.stride + 1;
@@ -347,15 +372,15 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     {
         ProfScope ps(st, "conv_dma", flops, bytes);
         e = launch_conv_dma(a, o.cfg, st);
-    }
-    if (g_prof_on && !g_prof.empty() && g_prof.back().name == "conv_dma") {
-        std::string cfgs(conv_dma_last_config());
-        g_prof.back().name = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
-        static const bool shapes = getenv("LDS_PROF_SHAPES") != nullptr;      // per-shape breakdown for tuning sessions
-        if (shapes) {
-            char sh[96];
-            snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "");
-            g_prof.back().name += sh;
+        if (ps.on) {
+            std::string cfgs(conv_dma_last_config());
+            std::string nm = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
+                char sh[96];
+                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "");
+                nm += sh;
+            }
+            ps.rename(nm);
         }
     }
     if (e != hipSuccess)
@@ -622,12 +647,17 @@ static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
 // All UNet activations between kernels are K4P tensors (k4p.h): floats(C, T) = C * (T + 2) per batch element.
 struct UnetWs {
     float *e1, *emb, *tproj;
-    float4* part;
     float2* lnp;
     float* xin;
     std::vector<float*> skips;
     float *cur[2], *r, *h1, *sc, *ta, *tb, *upt, *gno, *qk, *v, *att, *ff;
     int ss_stride = 0;
+    // GroupNorm partial statistics of an activation buffer (written by its producer's epilogue, read by gn_stream)
+    std::map<const float*, float2*> gpart;
+    float2* gp(const float* act) const {
+        auto it = gpart.find(act);
+        return it == gpart.end() ? nullptr : it->second;
+    }
 };
 
 static size_t k4(int C, int T) { return (size_t)C * (T + 2); }
@@ -638,21 +668,29 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.e1 = A.f((size_t)B * u->temb);
     w.emb = A.f((size_t)B * u->temb);
     w.tproj = A.f((size_t)B * u->tp_M);
-    w.part = (float4*)A.f((size_t)B * (u->max_ci / 8) * 4);
     w.xin = A.f(B * k4(u->M + u->H, T));
     std::vector<int> Ts{T};
     for (int i = 0; i < nb - 1; ++i) Ts.push_back(down_len(Ts.back()));
     size_t maxct = 0, maxgn = k4(boc[0], T), maxatt = 0;      // k4(C, T) = C * (T + 2) also covers the VT layout's C * ceil4(T) up to C floats
+    size_t maxgp = 0;                                          // GroupNorm partials of one activation: (C/16) * ceil(T/32) float2 per utterance
+    auto gpn = [](int C, int Tl) { return (size_t)(C / 16) * ((Tl + 31) / 32) * 2; };
+    w.gpart.clear();
+    auto act = [&](int C, int Tl) {                            // an exactly-sized activation buffer + its partials
+        float* p = A.f(B * k4(C, Tl));
+        w.gpart[p] = (float2*)A.f(B * gpn(C, Tl));
+        return p;
+    };
     w.skips.clear();
-    w.skips.push_back(A.f(B * k4(boc[0], T)));
+    w.skips.push_back(act(boc[0], T));
     for (int i = 0; i < nb; ++i) {
         const int Tl = Ts[i];
         maxct = std::max(maxct, k4(boc[i], Tl));
+        maxgp = std::max(maxgp, gpn(boc[i], Tl));
         maxgn = std::max(maxgn, k4(boc[i], Tl));
         if (i > 0) maxgn = std::max(maxgn, k4(boc[i - 1], Tl));
         if (i != nb - 1) maxatt = std::max(maxatt, k4(boc[i], Tl));
-        for (int j = 0; j < L; ++j) w.skips.push_back(A.f(B * k4(boc[i], Tl)));
-        if (i != nb - 1) w.skips.push_back(A.f(B * k4(boc[i], Ts[i + 1])));
+        for (int j = 0; j < L; ++j) w.skips.push_back(act(boc[i], Tl));
+        if (i != nb - 1) w.skips.push_back(act(boc[i], Ts[i + 1]));
     }
     maxatt = std::max(maxatt, k4(boc[nb - 1], Ts[nb - 1]));
     // up path: block i works at resolution nb-1-i with out channels boc[nb-1-i]; resnet inputs are (hidden + skip) channels
@@ -661,15 +699,21 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
         for (int i = 0; i < nb; ++i) {
             const int lvl = nb - 1 - i, co = boc[lvl], Tl = Ts[lvl];
             maxct = std::max(maxct, k4(co, Tl));
-            if (lvl > 0) maxct = std::max(maxct, k4(co, Ts[lvl - 1]));
+            maxgp = std::max(maxgp, gpn(co, Tl));
+            if (lvl > 0) { maxct = std::max(maxct, k4(co, Ts[lvl - 1])); maxgp = std::max(maxgp, gpn(co, Ts[lvl - 1])); }
             if (i != 0) maxatt = std::max(maxatt, k4(co, Tl));
             maxgn = std::max(maxgn, k4(prev + boc[nb - 1], Tl));   // upper bound: hidden + widest skip
             maxgn = std::max(maxgn, k4(2 * std::max(prev, co), Tl));
             prev = co;
         }
     }
-    w.cur[0] = A.f(B * maxct); w.cur[1] = A.f(B * maxct);
-    w.r = A.f(B * maxct); w.h1 = A.f(B * maxct); w.sc = A.f(B * maxct);
+    auto scratch = [&]() {                                     // a maximum-sized activation buffer + its partials
+        float* p = A.f(B * maxct);
+        w.gpart[p] = (float2*)A.f(B * maxgp);
+        return p;
+    };
+    w.cur[0] = scratch(); w.cur[1] = scratch();
+    w.r = scratch(); w.h1 = scratch(); w.sc = A.f(B * maxct);
     w.ta = A.f(B * maxct); w.tb = A.f(B * maxct); w.upt = A.f(B * maxct);
     w.gno = A.f(B * maxgn);
     w.qk = A.f(B * maxatt * 2); w.v = A.f(B * (maxatt + 2048)); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
@@ -689,10 +733,11 @@ extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t*
 static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, const float* x1, int C1, const float* x2, int C2, int T,
                       float* out, int B, hipStream_t st) {
     // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut.
-    // GroupNorm(+scale/shift)+SiLU is materialised once (gn_apply) so the convolutions stay VALU-free.
-    HIP_TRY(launch_gn_apply(x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.part, w.gno, B, st));
+    // GroupNorm(+scale/shift)+SiLU is materialised once per tensor by a streaming pass (gn_stream) so the convolutions stay
+    // VALU-free; its statistics come from the partials the producers of x1 / x2 / h1 wrote in their epilogues.
+    HIP_TRY(launch_gn_stream(x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.gp(x1), x2 ? w.gp(x2) : nullptr, w.gno, B, st));
     DOpt o1;
-    o1.pad = 1;
+    o1.pad = 1; o1.gnpart_out = w.gp(w.h1);
     LDS_TRY(run_dconv(r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
     const float* res = x1;
     if (r.has_sc) {
@@ -700,9 +745,10 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
         LDS_TRY(run_dconv(r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));   // skip-concat on read: second source pointer
         res = w.sc;
     }
-    HIP_TRY(launch_gn_apply(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.part, w.gno, B, st));
+    HIP_TRY(launch_gn_stream(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr,
+                             w.gno, B, st));
     DOpt o2;
-    o2.pad = 1; o2.res = res;
+    o2.pad = 1; o2.res = res; o2.gnpart_out = w.gp(out);
     return run_dconv(r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
 }
 
@@ -711,7 +757,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer (QKV / FF1) combines them per column and
     // applies the LayerNorm in its epilogue (weights pre-multiplied by gamma, pack_ln_fold).
     const int C = t.C;
-    HIP_TRY(launch_gn_apply(x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.part, w.gno, B, st));
+    HIP_TRY(launch_gn_stream(x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
     DOpt op;
     op.lnpart_out = w.lnp;
     LDS_TRY(run_dconv(t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
@@ -736,7 +782,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     o2.res = h;
     LDS_TRY(run_dconv(t.ff2, w.ff, 4 * C, nullptr, 0, T, o2, hn, B, st));
     DOpt o3;
-    o3.res = x;
+    o3.res = x; o3.gnpart_out = w.gp(out);
     return run_dconv(t.proj_out, hn, C, nullptr, 0, T, o3, out, B, st);
 }
 
@@ -787,7 +833,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     size_t si = 0;
     {
         DOpt o;
-        o.pad = 1;
+        o.pad = 1; o.gnpart_out = w.gp(w.skips[si]);
         LDS_TRY(run_dconv(u->conv_in, w.xin, cin, nullptr, 0, T, o, w.skips[si], B, st));
     }
     const float* cur = w.skips[si++];
@@ -806,7 +852,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
         }
         if (d.has_down) {
             DOpt o;
-            o.pad = 1; o.stride = 2;
+            o.pad = 1; o.stride = 2; o.gnpart_out = w.gp(w.skips[si]);
             LDS_TRY(run_dconv(d.down, cur, d.ch, nullptr, 0, Tl, o, w.skips[si], B, st));
             Tl = down_len(Tl);
             cur = w.skips[si++];
@@ -837,7 +883,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             const int Tn = skipT[si - 1];
             float* dst = w.cur[ci ^ 1];
             DOpt o;
-            o.pad = 1;
+            o.pad = 1; o.gnpart_out = w.gp(dst);
             if (Tn == 2 * Tl) {
                 o.ups = 1;
                 LDS_TRY(run_dconv(b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
@@ -852,7 +898,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     }
     // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031); eps leaves in the caller's frame-major layout
     const int c0 = u->cfg.block_out_channels[0];
-    HIP_TRY(launch_gn_apply(cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.part, w.gno, B, st));
+    HIP_TRY(launch_gn_stream(cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.gp(cur), nullptr, w.gno, B, st));
     DOpt o;
     o.pad = 1; o.out_plain = 1;
     return run_dconv(u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st);
@@ -1362,18 +1408,52 @@ extern "C" int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C
     hipStream_t st = (hipStream_t)stream;
     Owner own;
     TmpDev tmp;
-    const int C = C1 + C2;
+    const int C = C1 + C2, nT = (T + 31) / 32;
     float* g = up_vec(own, gamma, C);
     float* be = up_vec(own, beta, C);
     float* k1 = tmp.f((size_t)B * C1 * (T + 2));
     float* k2 = C2 ? tmp.f((size_t)B * C2 * (T + 2)) : nullptr;
     float* ky = tmp.f((size_t)B * C * (T + 2));
-    float* part = tmp.f((size_t)B * (C / 8) * 4);
-    if (!g || !be || !k1 || (C2 && !k2) || !ky || !part) return fail(LDS_ENOMEM, "alloc");
+    float* p1 = tmp.f((size_t)B * (C1 / 16) * nT * 2);
+    float* p2 = C2 ? tmp.f((size_t)B * (C2 / 16) * nT * 2) : nullptr;
+    if (!g || !be || !k1 || (C2 && (!k2 || !p2)) || !ky || !p1) return fail(LDS_ENOMEM, "alloc");
     HIP_TRY(launch_to_k4p(x1, k1, B, C1, T, C1, 0, st));
-    if (C2) HIP_TRY(launch_to_k4p(x2, k2, B, C2, T, C2, 0, st));
-    HIP_TRY(launch_gn_apply(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (float4*)part, ky, B, st));
+    HIP_TRY(launch_gn_partials(k1, C1, T, (float2*)p1, B, st));
+    if (C2) {
+        HIP_TRY(launch_to_k4p(x2, k2, B, C2, T, C2, 0, st));
+        HIP_TRY(launch_gn_partials(k2, C2, T, (float2*)p2, B, st));
+    }
+    HIP_TRY(launch_gn_stream(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (const float2*)p1, (const float2*)p2, ky, B, st));
     HIP_TRY(launch_from_k4p(ky, out, B, C, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
+// mid = conv1x1(x) written with the epilogue's GroupNorm partials; out = GroupNorm(mid) by the streaming pass that combines
+// those partials (the statistics path the UNet uses)
+extern "C" int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,
+                                     int groups, int silu, float* mid, float* out, int B, int C, int Co, int T, int cfg, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    TmpDev tmp;
+    ConvW W1;
+    if (!pack_conv(own, w1, bias1, Co, C, 1, W1)) return fail(LDS_ENOMEM, "upload failed");
+    float* g = up_vec(own, gamma, Co);
+    float* be = up_vec(own, beta, Co);
+    const int nT = (T + 31) / 32;
+    float* kx = tmp.f((size_t)B * C * (T + 2));
+    float* km = tmp.f((size_t)B * Co * (T + 2));
+    float* ko = tmp.f((size_t)B * Co * (T + 2));
+    float* gp = tmp.f((size_t)B * (Co / 16) * nT * 2);
+    if (!g || !be || !kx || !km || !ko || !gp) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(hipMemsetAsync(gp, 0xff, sizeof(float) * B * (Co / 16) * nT * 2, st));      // NaN fill: every partial must be written
+    HIP_TRY(launch_to_k4p(x, kx, B, C, T, C, 0, st));
+    DOpt o1;
+    o1.gnpart_out = (float2*)gp; o1.cfg = cfg;
+    LDS_TRY(run_dconv(W1, kx, C, nullptr, 0, T, o1, km, B, st));
+    HIP_TRY(launch_gn_stream(km, nullptr, Co, 0, T, groups, eps, g, be, nullptr, 0, 0, silu, (const float2*)gp, nullptr, ko, B, st));
+    HIP_TRY(launch_from_k4p(km, mid, B, Co, T, st));
+    HIP_TRY(launch_from_k4p(ko, out, B, Co, T, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
 }

@@ -37,14 +37,16 @@ class UNet1DConditionModel(ParamTree):
         self.in_channels, self.out_channels = in_channels, out_channels
         self._native = None
 
-    # any change of the parameters (load_state_dict, .to(), manual edits via _apply) drops the packed copy
+    # Any change of the parameters drops the packed copy: .to()/.float() go through _apply; load_state_dict -- called on
+    # this module OR on any parent (Unit2Mel / GaussianDiffusion: nn.Module.load_state_dict recurses through the children's
+    # _load_from_state_dict, never their load_state_dict) -- goes through _load_from_state_dict of this root node.
     def _apply(self, fn, *a, **k):
         self._native = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):
         self._native = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def native(self):
         if self._native is None:

@@ -85,9 +85,9 @@ class Unit2Mel(nn.Module):
         self._embed = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):      # reached from load_state_dict of this module or of any parent
         self._embed = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def _native_embed(self):
         if self._embed is None:
@@ -104,6 +104,16 @@ class Unit2Mel(nn.Module):
             raise NotImplementedError("aug_shift_embed is None in the reference (unit2mel.py:54)")
         if self.n_spk is not None and self.n_spk > 1 and spk_id is None:
             raise TypeError("spk_id is required when n_spk > 1 (reference unit2mel.py:81-82)")
+        if self.n_spk is not None and self.n_spk > 1:
+            # nn.Embedding(spk_id - 1) raises IndexError for ids outside [1, n_spk] (reference unit2mel.py:82).  Ids that
+            # arrive on the host are checked here; ids already on the device are checked by the gather kernel, which writes
+            # NaN rows for them (no device->host synchronisation on the hot path).
+            if not torch.is_tensor(spk_id):
+                spk_id = torch.as_tensor(spk_id, dtype=torch.int64).reshape(units.shape[0], -1)
+            if not spk_id.is_cuda:
+                if bool(((spk_id < 1) | (spk_id > self.n_spk)).any()):
+                    raise IndexError("index out of range in self")
+                spk_id = spk_id.to(units.device)
         # x = unit_embed(units) + spk_embed(spk_id - 1), produced channel-major by liblds
         cond = self._native_embed().forward(units.contiguous().float(), spk_id)        # [B,H,T]
         x = native.transpose(cond)                                                     # [B,T,H] as the reference hands over

@@ -1,9 +1,9 @@
 """Utterance-batch sharding across the GPUs of one node (one process per GPU).
 
 The sampler path is embarrassingly parallel over utterances (every op is per-sample, SURVEY.md
-8e), so the only communication is moving inputs to the ranks and results back: RCCL
-broadcast / scatter / gather over xGMI through torch.distributed (backend "nccl" on ROCm;
-"gloo" on CPU in the tests).  No collective runs inside the sampler loop."""
+8e), so the only communication is moving inputs to the ranks and results back: an RCCL scatter of
+the input shards and a gather of the results over xGMI through torch.distributed (backend "nccl"
+on ROCm; "gloo" on CPU in the tests).  No collective runs inside the sampler loop."""
 import torch
 import torch.distributed as dist
 
@@ -15,41 +15,59 @@ def shard_range(n_items, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def scatter_batch(full, rank, world, src=0, shape=None):
-    """Rank `src` holds `full` [N, ...]; every rank returns its shard [n_r, ...].
-    One broadcast of the batch (RCCL broadcast over xGMI on the GPU box) + a local slice: the same code path for
-    even and ragged splits, and only collectives every backend implements.  `shape` = the full shape when every rank
-    knows it (saves the object broadcast)."""
+def _meta(full, rank, src, shape, dtype):
+    """(shape, dtype) of the full batch on every rank; one object broadcast unless the caller supplied both."""
+    if shape is not None and dtype is not None:
+        return tuple(shape), dtype
+    box = [(tuple(full.shape), full.dtype) if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return tuple(box[0][0]), box[0][1]
+
+
+def scatter_batch(full, rank, world, src=0, shape=None, dtype=None, device=None):
+    """Rank `src` holds `full` [N, ...]; every rank returns its shard [n_r, ...] (contiguous balanced split).
+    One scatter: each rank receives only its own rows (42 MB of units per rank at B=16 x 512 frames, instead of the
+    whole batch).  Ragged splits pad every shard to the largest one.  `shape` / `dtype` = those of the full batch when
+    every rank knows them (saves the object broadcast); `device` = where non-src ranks allocate (default: full.device)."""
     if world == 1:
         return full
-    if shape is None:
-        box = [tuple(full.shape) if rank == src else None]
-        dist.broadcast_object_list(box, src=src)
-        shape = box[0]
-    shp = tuple(shape)
-    buf = full.contiguous() if rank == src else torch.empty(shp, dtype=torch.float32, device=full.device)
-    dist.broadcast(buf, src=src)
-    lo, hi = shard_range(shp[0], rank, world)
-    return buf[lo:hi].contiguous()
+    shp, dt = _meta(full, rank, src, shape, dtype)
+    dev = device if device is not None else full.device
+    n = shp[0]
+    mx = -(-n // world)
+    lo, hi = shard_range(n, rank, world)
+    recv = torch.empty((mx,) + shp[1:], dtype=dt, device=dev)
+    parts = None
+    if rank == src:
+        if full.dtype != dt or tuple(full.shape) != shp:
+            raise ValueError(f"scatter_batch: full is {tuple(full.shape)} {full.dtype}, announced {shp} {dt}")
+        parts = []
+        for r in range(world):
+            a, b = shard_range(n, r, world)
+            p = full[a:b]
+            if b - a < mx:                                 # ragged: pad to the common shard size
+                p = torch.cat([p, p.new_zeros((mx - (b - a),) + shp[1:])])
+            parts.append(p.contiguous())
+    dist.scatter(recv, parts, src=src)
+    return recv[: hi - lo].contiguous() if hi - lo < mx else recv
 
 
 def gather_batch(local, rank, world, dst=0, sizes=None):
-    """Concatenate per-rank results [n_r, ...] on rank `dst` (equal n_r -> all_gather_into_tensor).
+    """Concatenate per-rank results [n_r, ...] on rank `dst` (None elsewhere): one gather to `dst`.
     `sizes` = the per-rank n_r when the caller knows them (saves the object collective and its host synchronisation)."""
     if world == 1:
         return local
     if sizes is None:
         sizes = [None] * world
         dist.all_gather_object(sizes, int(local.shape[0]))
-    if len(set(sizes)) == 1:
-        out = torch.empty((sum(sizes),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous())
-        return out if rank == dst else None
     mx = max(sizes)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad)
+    send = local.contiguous()
+    if send.shape[0] < mx:
+        send = torch.cat([send, send.new_zeros((mx - send.shape[0],) + tuple(send.shape[1:]))])
+    outs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, outs, dst=dst)
     if rank != dst:
         return None
+    if len(set(sizes)) == 1:
+        return torch.cat(outs)
     return torch.cat([o[:s] for o, s in zip(outs, sizes)])

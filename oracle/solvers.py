@@ -204,6 +204,12 @@ def plms(eps_fn, bufs, x, k_step, speedup):
     return x
 
 
+def q_sample(bufs, x_start, t, noise):
+    """q_sample (diffusion.py:169-171) at the scalar step t: sqrt(ac_t) * x_start + sqrt(1 - ac_t) * noise.
+    The shallow-diffusion entry (diffusion.py:207-211) starts the sampler from q_sample(norm_spec(gt_spec), k_step - 1)."""
+    return (bufs["sqrt_alphas_cumprod"][t] * x_start.astype(f32) + bufs["sqrt_one_minus_alphas_cumprod"][t] * noise.astype(f32)).astype(f32)
+
+
 def sample(eps_fn, bufs, x_T, method, infer_speedup, k_step=1000, noise=None):
     """GaussianDiffusion.forward(infer=True) dispatch (diffusion.py:203-343), x_T injected.
     x_T: [B,M,T]; returns x_0 [B,M,T] (before the final transpose / acoustic_scale)."""

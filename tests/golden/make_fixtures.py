@@ -1,7 +1,7 @@
 """Generate golden fixtures by importing the reference's runnable leaf modules.
 
 Runs ONLY in the build container (needs /root/reference); the GPU box never sees the
-reference.  Writes small .npz/.json files next to this script:
+reference.  Writes small .npz/.json files (default: next to this script, `--out DIR` elsewhere):
 
   manifest_unet.json / manifest_generator.json  state_dict key -> shape of the reference modules
   schedule.npz        GaussianDiffusion schedule buffers (reference diffusion/diffusion.py:46-87)
@@ -9,13 +9,25 @@ reference.  Writes small .npz/.json files next to this script:
                       T multiple of 8 and not; a few intermediate activations
   solver_toy.npz      DPM-Solver++(2M) / UniPC-bh2 trajectories with an analytic eps model
   sampler.npz         GaussianDiffusion.forward(infer=True) for dpm-solver/unipc/ddim/pndm/ddpm
+  sampler_shallow.npz the shallow-diffusion entry (gt_spec + k_step, reference diffusion.py:203-211) for every
+                      method with k_step != 1000: outputs stay O(1), DDPM without clamp saturation
   vocoder.npz         Generator forward (synthetic h), weight-norm checkpoint
+  vocoder_rb2.npz     Generator forward with resblock '2' (reference models.py:201-222)
 
 Weights always come from the build-owned seeded initialiser (lds/init_weights.py) loaded
 into the reference modules with load_state_dict, so they can be regenerated anywhere.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py
+Import hygiene: the product package has modules with the reference's names (`diffusion`, `encoder`, `tools`), so the
+product directory is NEVER put on sys.path here.  Only /root/reference is, the two data-only product helpers
+(lds/arch.py, lds/init_weights.py: parameter shapes and the integer-only RNG) are loaded by file path under
+private names, and every reference class used is asserted to come from a file under /root/reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py [--out DIR]
+tests/golden/verify_fixtures.py regenerates into a temporary directory and checks bit-identity with the committed files.
 """
+import argparse
+import importlib.util
+import inspect
 import json
 import os
 import sys
@@ -25,13 +37,26 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, os.path.join(ROOT, "latent-diffusion-speech_amd"))
-sys.path.insert(1, "/root/reference")
+PKG = os.path.join(ROOT, "latent-diffusion-speech_amd")
+REF = "/root/reference"
 sys.dont_write_bytecode = True
 
-import torch  # noqa: E402
 
-from lds import arch, init_weights  # noqa: E402
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+arch = _load_by_path("_amd_arch", os.path.join(PKG, "lds", "arch.py"))
+init_weights = _load_by_path("_amd_init_weights", os.path.join(PKG, "lds", "init_weights.py"))
+
+# the reference, and only the reference, is importable by package name
+sys.path[:] = [p for p in sys.path if os.path.realpath(p or ".") not in (os.path.realpath(PKG), os.path.realpath(ROOT))]
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
 
 torch.set_grad_enabled(False)
 torch.set_num_threads(8)
@@ -54,6 +79,17 @@ from diffusion.unet1d.unet_1d_condition import UNet1DConditionModel  # noqa: E40
 from diffusion import dpm_solver_pytorch, uni_pc  # noqa: E402
 from encoder.hifi_vaegan.modules.models import Generator  # noqa: E402
 
+
+def reference_origin():
+    """name -> source file of every reference object the fixtures are produced with"""
+    objs = {"GaussianDiffusion": GaussianDiffusion, "UNet1DConditionModel": UNet1DConditionModel,
+            "dpm_solver_pytorch": dpm_solver_pytorch, "uni_pc": uni_pc, "Generator": Generator}
+    return {k: os.path.realpath(inspect.getfile(v)) for k, v in objs.items()}
+
+
+for _name, _file in reference_origin().items():
+    assert _file.startswith(REF + os.sep), f"{_name} was imported from {_file}, not from the reference"
+
 SEED_W = 0
 
 
@@ -75,16 +111,56 @@ def build_unet():
     return cfg, m
 
 
+class RecordedDraws:
+    """Replace torch.randn / torch.randn_like by recording versions (seeded CPU generator) for one sampler call."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        self.drawn = []
+
+    def __enter__(self):
+        self.real = (torch.randn, torch.randn_like)
+        real_randn, real_like = self.real
+
+        def rec_randn(*a, **k):
+            k.pop("device", None)
+            v = real_randn(*a, **k)
+            self.drawn.append(v.numpy().copy())
+            return v
+
+        def rec_like(x, **k):
+            v = real_like(x, **k)
+            self.drawn.append(v.numpy().copy())
+            return v
+        torch.manual_seed(self.seed)
+        torch.randn, torch.randn_like = rec_randn, rec_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self.real
+
+    def stacked(self):
+        return np.stack([d.reshape(self.drawn[0].shape) for d in self.drawn])
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE)
+    out_dir = ap.parse_args().out
+    os.makedirs(out_dir, exist_ok=True)
+
+    def path(name):
+        return os.path.join(out_dir, name)
+
     cfg, unet = build_unet()
     man = {k: list(v.shape) for k, v in unet.state_dict().items()}
-    json.dump(man, open(os.path.join(HERE, "manifest_unet.json"), "w"), indent=0)
+    json.dump(man, open(path("manifest_unet.json"), "w"), indent=0)
 
     gd = GaussianDiffusion(unet, out_dims=80)
     sched = {k: v.numpy() for k, v in gd.state_dict().items() if not k.startswith("denoise_fn.")}
-    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **sched)
+    np.savez_compressed(path("schedule.npz"), **sched)
     json.dump({k: list(v.shape) for k, v in gd.state_dict().items() if not k.startswith("denoise_fn.")},
-              open(os.path.join(HERE, "manifest_diffusion_buffers.json"), "w"), indent=0)
+              open(path("manifest_diffusion_buffers.json"), "w"), indent=0)
 
     # ---------------- UNet forward -------------------------------------------------
     out = {}
@@ -120,7 +196,7 @@ def main():
         for k, v in caught.items():
             out[f"{case}_tap_{k}"] = v
         print("unet case", case, y.shape, float(np.abs(y).max()))
-    np.savez_compressed(os.path.join(HERE, "unet_fwd.npz"), **out)
+    np.savez_compressed(path("unet_fwd.npz"), **out)
 
     # ---------------- solver algebra with an analytic eps model ---------------------
     B, M, T = 2, 80, 8
@@ -154,32 +230,27 @@ def main():
     toyres["grid50_sigma"] = torch.stack([ns.marginal_std(t[None]) for t in ts]).reshape(-1).numpy()
     toyres["grid50_lambda"] = torch.stack([ns.marginal_lambda(t[None]) for t in ts]).reshape(-1).numpy()
     toyres["log_alpha_array"] = ns.log_alpha_array.numpy()
-    np.savez_compressed(os.path.join(HERE, "solver_toy.npz"), **toyres)
+    np.savez_compressed(path("solver_toy.npz"), **toyres)
     print("toy solver done")
 
     # ---------------- full sampler through GaussianDiffusion.forward ----------------
     B, T = 2, 32
     condBT = init_weights.uniform("fix.samp.cond", (B, T, 256), 13, -1.0, 1.0)
     res = {"cond": condBT}
-    real_randn = torch.randn
 
-    def run(method, speedup, k_step=None, B_=B, seed=2):
-        drawn = []
-
-        def rec_randn(*a, **k):
-            k.pop("device", None)
-            v = real_randn(*a, **k)
-            drawn.append(v.numpy().copy())
-            return v
-        torch.manual_seed(seed)
-        torch.randn = rec_randn
-        try:
-            gd.k_step = 1000 if k_step is None else k_step
-            y = gd(tt(condBT[:B_]), infer=True, infer_speedup=speedup, method=method).numpy()
-        finally:
-            torch.randn = real_randn
-            gd.k_step = 1000
-        return y, np.stack([d.reshape(drawn[0].shape) for d in drawn])
+    def run(method, speedup, k_step=None, B_=B, seed=2, gt_spec=None):
+        with RecordedDraws(seed) as rec:
+            try:
+                if gt_spec is None:
+                    gd.k_step = 1000 if k_step is None else k_step
+                    y = gd(tt(condBT[:B_]), infer=True, infer_speedup=speedup, method=method).numpy()
+                else:
+                    # shallow entry: x = q_sample(norm_spec(gt_spec), k_step - 1), schedules cut to betas[:k_step]
+                    y = gd(tt(condBT[:B_]), gt_spec=tt(gt_spec[:B_]), infer=True, infer_speedup=speedup, method=method,
+                           k_step=k_step).numpy()
+            finally:
+                gd.k_step = 1000
+        return y, rec.stacked()
 
     for name, (method, speedup, k_step, b_) in {
         "dpm50": ("dpm-solver", 20, None, B),
@@ -192,21 +263,49 @@ def main():
         res[name + "_y"] = y
         res[name + "_noise"] = noise
         print("sampler", name, y.shape, noise.shape, float(np.abs(y).max()))
-    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **res)
+    np.savez_compressed(path("sampler.npz"), **res)
+
+    # ---------------- shallow-diffusion entry (gt_spec + k_step) ---------------------
+    gt = init_weights.uniform("fix.shallow.gt", (B, T, 80), 15, -0.6, 0.6)
+    res = {"cond": condBT, "gt_spec": gt}
+    for name, (method, speedup, k_step, b_) in {
+        "dpm20": ("dpm-solver", 10, 200, B),      # 20 NFE on betas[:200]
+        "unipc10": ("unipc", 20, 200, B),
+        "ddim8": ("ddim", 25, 200, B),
+        "pndm8": ("pndm", 25, 200, 1),
+        "ddpm12": (None, 1, 12, B),
+    }.items():
+        y, noise = run(method, speedup, k_step, b_, seed=3, gt_spec=gt)
+        res[name + "_y"] = y
+        res[name + "_noise"] = noise       # draw 0 = q_sample's randn_like, then the per-step DDPM draws
+        print("shallow", name, y.shape, noise.shape, "absmax", float(np.abs(y).max()), "frac |y|>=1:", float((np.abs(y) >= 1).mean()))
+    np.savez_compressed(path("sampler_shallow.npz"), **res)
 
     # ---------------- vocoder -------------------------------------------------------
     h = arch.SYNTHETIC_VOCODER_H
     g = Generator(h)
     gsh = arch.generator_param_shapes(h)
     json.dump({k: list(v.shape) for k, v in g.state_dict().items()},
-              open(os.path.join(HERE, "manifest_generator.json"), "w"), indent=0)
+              open(path("manifest_generator.json"), "w"), indent=0)
     g.load_state_dict({k: tt(v) for k, v in init_weights.init_state(gsh, SEED_W).items()}, strict=True)
     g.eval()
     g.remove_weight_norm()
     z = init_weights.uniform("fix.voc.z", (2, 12, 80), 14, -1.5, 1.5)     # mel layout [B,T,C]
     wav = g(tt(z).transpose(-1, -2)).numpy()
     print("vocoder", wav.shape, float(np.abs(wav).max()))
-    np.savez_compressed(os.path.join(HERE, "vocoder.npz"), z=z, wav=wav)
+    np.savez_compressed(path("vocoder.npz"), z=z, wav=wav)
+
+    # resblock '2' (two dilated convs per block, no second conv)
+    h2 = dict(h, resblock="2", resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
+    g2 = Generator(h2)
+    g2.load_state_dict({k: tt(v) for k, v in init_weights.init_state(arch.generator_param_shapes(h2), SEED_W).items()}, strict=True)
+    g2.eval()
+    g2.remove_weight_norm()
+    z2 = init_weights.uniform("fix.voc2.z", (2, 10, 80), 14, -1.5, 1.5)
+    wav2 = g2(tt(z2).transpose(-1, -2)).numpy()
+    print("vocoder rb2", wav2.shape, float(np.abs(wav2).max()))
+    np.savez_compressed(path("vocoder_rb2.npz"), z=z2, wav=wav2,
+                        h_json=np.frombuffer(json.dumps(h2, sort_keys=True).encode(), dtype=np.uint8))
 
 
 if __name__ == "__main__":

@@ -48,6 +48,11 @@ def _worker(rank, world, port, n_items, q):
         else:
             ok = ok and out is None
         ok = ok and ok2
+        # integer payloads (speaker ids): dtype announced by the caller or broadcast with the shape
+        ids = (torch.arange(n_items, dtype=torch.int64) * 3 + 1).reshape(n_items, 1)
+        mine3 = shard.scatter_batch(ids if rank == 0 else torch.empty(0), rank, world, shape=(n_items, 1), dtype=torch.int64)
+        mine4 = shard.scatter_batch(ids if rank == 0 else torch.empty(0), rank, world)
+        ok = ok and mine3.dtype == torch.int64 and torch.equal(mine3, ids[lo:hi]) and torch.equal(mine4, ids[lo:hi])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -171,3 +171,99 @@ def test_checkpoint_formats_and_facade(tmp_path, unit2mel_gpu, monkeypatch):
     assert wav.shape == (B, 1, T * 512) and bool(torch.isfinite(wav).all())
     mel = unit2mel_gpu(units, None, spk_id=torch.full((B, 1), 5, device="cuda"), infer=True, infer_speedup=250, method="dpm-solver")
     assert torch.equal(svc.vocoder.infer(mel), wav)            # same weights through both loaders -> identical result
+
+
+@pytest.mark.parametrize("name,method,speedup,k_step,B", [
+    ("dpm20", "dpm-solver", 10, 200, 2), ("unipc10", "unipc", 20, 200, 2), ("ddim8", "ddim", 25, 200, 2),
+    ("pndm8", "pndm", 25, 200, 1), ("ddpm12", None, 1, 12, 2)])
+def test_sampler_shallow_vs_reference(golden, unit2mel_gpu, monkeypatch, name, method, speedup, k_step, B):
+    """Shallow-diffusion entry of GaussianDiffusion.forward (reference diffusion.py:203-211): gt_spec + k_step ->
+    x = q_sample(norm_spec(gt_spec), k_step - 1), every solver on the cut schedule betas[:k_step].  The reference's
+    outputs stay O(1) here (|y| <= 3.5; the DDPM case never reaches the clamp), so 1e-4 * absmax is ~3e-4 absolute."""
+    g = golden("sampler_shallow.npz")
+    gd = unit2mel_gpu.decoder
+    draws = [dev(n) for n in g[name + "_noise"]]      # draw 0 = q_sample's randn_like, then the DDPM per-step draws
+
+    def fake(*a, **k):
+        return draws.pop(0)
+    monkeypatch.setattr(torch, "randn", fake)
+    monkeypatch.setattr(torch, "randn_like", fake)
+    y = gd(dev(g["cond"][:B]), gt_spec=dev(g["gt_spec"][:B]), infer=True, infer_speedup=speedup, method=method, k_step=k_step).cpu().numpy()
+    assert not draws
+    ref = g[name + "_y"]
+    assert y.shape == ref.shape and np.abs(ref).max() < 4.0
+    assert relmax(y, ref) < 1e-4, relmax(y, ref)
+
+
+def test_vocoder_resblock2_vs_reference(golden):
+    """Generator with resblock '2' (reference models.py:201-222,230): one dilated conv per residual step"""
+    import json
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights
+    g = golden("vocoder_rb2.npz")
+    h = json.loads(bytes(g["h_json"]).decode())
+    voc = Hifi_VAEGAN(None, device="cuda", h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
+    wav = voc(dev(g["z"])).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    assert relmax(wav, g["wav"]) < 1e-4, relmax(wav, g["wav"])
+
+
+def test_unet_full_size_vs_oracle(unit2mel_gpu, unet_weights):
+    """BASELINE size: one T = 512 utterance-forward (every level's real tile shapes: 512/256/128/64 frames) against the
+    numpy oracle, plus a second utterance in the same launch with another (fractional) timestep."""
+    from lds import init_weights
+    from oracle import unet1d
+    cfg, blocks, w = unet_weights
+    unet = unit2mel_gpu.decoder.denoise_fn
+    x = init_weights.uniform("full.x", (2, 336, 512), 41, -2, 2)
+    t = np.array([873.25, 40.5], dtype=np.float32)
+    got = unet(dev(x), dev(t)).sample.cpu().numpy()
+    ref = unet1d.unet_forward(w, cfg, blocks, x[:1], t[:1])
+    assert relmax(got[:1], ref) < 2e-5, relmax(got[:1], ref)
+    ref1 = unet1d.unet_forward(w, cfg, blocks, x[1:], t[1:])
+    assert relmax(got[1:], ref1) < 2e-5, relmax(got[1:], ref1)
+
+
+def test_vocoder_full_size_vs_oracle():
+    """128 mel frames -> 65,536 samples: every upsampling stage runs its real tile shapes (256@1024 ... 16@65536 columns,
+    the small-channel tail included) against the numpy oracle."""
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights
+    from oracle import vocoder as o_voc
+    h = arch.SYNTHETIC_VOCODER_H
+    state = init_weights.init_state(arch.generator_param_shapes(h), 0)
+    voc = Hifi_VAEGAN(None, device="cuda", h=h, state=state)
+    z = init_weights.uniform("full.voc.z", (1, 128, 80), 42, -1.5, 1.5)
+    wav = voc(dev(z)).cpu().numpy()
+    ref = o_voc.generator_forward(o_voc.fold_weight_norm(state), h, np.ascontiguousarray(z.transpose(0, 2, 1)))
+    assert wav.shape == ref.shape == (1, 1, 65536)
+    assert relmax(wav, ref) < 1e-4, relmax(wav, ref)
+
+
+def test_parent_load_state_dict_repacks_weights(unit2mel_gpu):
+    """nn.Module.load_state_dict on a PARENT recurses through the children's _load_from_state_dict, never their
+    load_state_dict: after a forward has packed the weights, loading other weights through Unit2Mel must drop the
+    packed copies of the UNet and of the front end (reference behaviour: load_model_vocoder -> model.load_state_dict)."""
+    from diffusion.unit2mel import Unit2Mel
+    from lds import init_weights
+    m = Unit2Mel(1280, 323, 80).to("cuda").eval()
+    B, T = 1, 16
+    units = dev(init_weights.uniform("reload.units", (B, T, 1280), 3, -1.7, 1.7))
+    x = dev(init_weights.uniform("reload.x", (B, 336, T), 3, -2, 2))
+    t = dev(np.array([100.0], dtype=np.float32))
+    spk = torch.full((B, 1), 5, device="cuda")
+    e0 = m.decoder.denoise_fn(x, t).sample.clone()
+    c0 = m._native_embed().forward(units, spk).clone()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["decoder.denoise_fn.conv_out.bias"] += 0.5
+    sd["unit_embed.bias"] += 0.25
+    m.load_state_dict(sd)
+    e1 = m.decoder.denoise_fn(x, t).sample
+    c1 = m._native_embed().forward(units, spk)
+    assert torch.allclose(e1, e0 + 0.5, atol=1e-5) and not torch.equal(e1, e0)
+    assert torch.allclose(c1, c0 + 0.25, atol=1e-5) and not torch.equal(c1, c0)
+    # and loading through the diffusion wrapper alone
+    sd2 = {k: v.clone() for k, v in m.decoder.state_dict().items()}
+    sd2["denoise_fn.conv_out.bias"] -= 0.5
+    m.decoder.load_state_dict(sd2)
+    assert torch.allclose(m.decoder.denoise_fn(x, t).sample, e0, atol=1e-5)
