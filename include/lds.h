@@ -170,6 +170,8 @@ int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int iters, float
                     void* stream);
 int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                       const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
+/* average time of one streaming-GroupNorm launch on zero-filled tensors (tools/bench_gn.py) */
+int lds_bench_gn_stream(int C1, int C2, int T, int B, int iters, float* ms_out, void* stream);
 /* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
  * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
 int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const long long off = ((long long)(q * 2 + hh) * Tp + tq + 1) * 4 + 2 * h;
-                    *reinterpret_cast<f32x2*>(ob + off) = f32x2{o[i][4 * g + hh] * rl, o[i][4 * g + 2 + hh] * rl};
+                    k4p_store_wt(ob + off, f32x2{o[i][4 * g + hh] * rl, o[i][4 * g + 2 + hh] * rl});      // write-through (k4p.h)
                     if (tq == 0) *reinterpret_cast<f32x2*>(ob + off - 4) = f32x2{0.f, 0.f};
                     if (tq == T - 1) *reinterpret_cast<f32x2*>(ob + off + 4) = f32x2{0.f, 0.f};
                 }

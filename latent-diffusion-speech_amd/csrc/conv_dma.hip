@@ -438,7 +438,7 @@ struct DmaKernel {
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
-                    *reinterpret_cast<f32x2*>(ob + (2 * g + hh) * Tpo * 4) = f32x2{acc[0][i][j][4 * g + hh], acc[0][i][j][4 * g + 2 + hh]};
+                    k4p_store_wt(ob + (2 * g + hh) * Tpo * 4, f32x2{acc[0][i][j][4 * g + hh], acc[0][i][j][4 * g + 2 + hh]});
             if (n == 0) {                     // left pad frame
 #pragma unroll
                 for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 - 4) = f32x2{0.f, 0.f};

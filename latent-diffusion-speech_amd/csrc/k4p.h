@@ -10,6 +10,7 @@
 //   linear copies (LDS-DMA).  Every kernel that writes a K4P tensor also writes its two pad frames.
 // * channel concatenation = concatenation of 8-channel blocks, so the UNet's skip-concat is a second base pointer.
 #pragma once
+#include <hip/hip_runtime.h>
 
 namespace lds {
 
@@ -17,5 +18,14 @@ __host__ __device__ inline long long k4p_index(int C, int T, int b, int c, int t
     return ((((long long)b * (C >> 3) + (c >> 3)) * 2 + (c & 1)) * (T + 2) + (t + 1)) * 4 + ((c & 7) >> 1);
 }
 __host__ __device__ inline long long k4p_floats(int B, int C, int T) { return (long long)B * C * (T + 2); }
+
+// 8-byte write-through store (global_store_dwordx2 ... sc1): the line goes to memory while the kernel is still computing
+// instead of staying dirty in the XCD's L2 until the end-of-kernel write-back, which the next launch has to wait for
+// (MI355X_MICROARCH.md price list, row "boundary": + bytes / 6 TB/s when the predecessor leaves dirty lines).  Every 64-byte
+// line of a K4P row is written whole by one wave instruction (lanes = consecutive frames, both lane halves fill an entry).
+typedef float k4p_f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void k4p_store_wt(float* p, k4p_f32x2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 }  // namespace lds

@@ -13,6 +13,7 @@
 namespace lds {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // one workgroup per (b, 8-channel block)
 __global__ void __launch_bounds__(256) to_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int Ctot, int c_off) {
@@ -90,7 +91,7 @@ static __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // Chan's parallel combination of (count, mean, M2); an empty side (count 0) is the identity
 static __device__ __forceinline__ void chan(float& n, float& mean, float& m2, float nb, float mb, float qb) {
     const float nn = n + nb;
-    const float r = (nn > 0.f) ? 1.0f / nn : 0.f;
+    const float r = (nn > 0.f) ? __builtin_amdgcn_rcpf(nn) : 0.f;      // counts are small integers: v_rcp_f32 is within 1 ulp
     const float d = mb - mean;
     mean += d * (nb * r);
     m2 += qb + d * d * (n * nb * r);
@@ -147,6 +148,7 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
     const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
     const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
     float* yb = y + (((long long)b * nq + q) * 2) * Tp * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yb, 0, 2 * Tp * 16, 0x00020000);
     const int total = 2 * T;                          // real entries of this block: (row hh, frame t) -> idx = hh * T + t
     // ---- 1. request the first chunk ----
     f32x4 v[E];
@@ -178,12 +180,13 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
     const int cg16 = (C / groups) >> 4;               // 16-channel blocks per group
     const int g = (q * 8) / (C / groups);
     const int nT = (T + 31) >> 5, P = cg16 * nT, nk1 = C1 >> 4;
+    const float inv_nT = 1.0f / (float)nT;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int p0 = 0; p0 < P; p0 += 64) {              // <= 2 rounds for every shape of the UNet
         const int pi = p0 + lane;
         float nb = 0.f, mb = 0.f, qb = 0.f;
         if (pi < P) {
-            const int kk = pi / nT, tb = pi - kk * nT, kb = g * cg16 + kk;
+            const int kk = (int)(((float)pi + 0.5f) * inv_nT), tb = pi - kk * nT, kb = g * cg16 + kk;      // pi / nT without the integer-division sequence
             const float2 pr = (kb < nk1) ? gp1[((long long)b * nk1 + kb) * nT + tb] : gp2[((long long)b * (C2 >> 4) + (kb - nk1)) * nT + tb];
             const int nv = (T - tb * 32 < 32) ? T - tb * 32 : 32;
             nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
@@ -232,7 +235,8 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
                     if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
                     o[j] = r;
                 }
-                *reinterpret_cast<f32x4*>(yb + ((long long)hh * Tp + t + 1) * 4) = o;
+                // write-through 16-byte store (sc1): no dirty lines left for the end-of-kernel write-back (k4p.h, k4p_store_wt)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)(((long long)hh * Tp + t + 1) * 16), 0, 16);
             }
         }
     }

@@ -403,7 +403,7 @@ struct TfmW {
     int C = 0;
     float *gn_g = nullptr, *gn_b = nullptr;
     float *qkv_c1[2] = {nullptr, nullptr}, *qkv_c2[2] = {nullptr, nullptr}, *ff1_c1 = nullptr, *ff1_c2 = nullptr;   // folded LayerNorm constants
-    ConvW proj_in, proj_out, qkv[2], o[2], ff1, ff2;
+    ConvW proj_in, qkv[2], o[2], ff1, ff2_out;      // ff2_out = ff.net.2 and proj_out composed (load_tfm)
 };
 struct DownBlk { std::vector<ResnetW> res; std::vector<TfmW> att; bool has_down = false; ConvW down; int ch = 0; };
 struct UpBlk { std::vector<ResnetW> res; std::vector<TfmW> att; std::vector<int> skip_ch; bool has_up = false; ConvW up; int ch = 0; };
@@ -470,7 +470,7 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
     const float* pow_ = T.get(p + "proj_out.weight", (int64_t)C * C);
     const float* pob = T.get(p + "proj_out.bias", C);
     if (!t.gn_g || !t.gn_b || !piw || !pib || !pow_ || !pob) return false;
-    if (!pack_conv(o, piw, pib, C, C, 1, t.proj_in) || !pack_conv(o, pow_, pob, C, C, 1, t.proj_out)) return false;
+    if (!pack_conv(o, piw, pib, C, C, 1, t.proj_in)) return false;
     const std::string b = p + "transformer_blocks.0.";
     const float *lg[3], *lb[3];
     for (int i = 0; i < 3; ++i) {
@@ -506,7 +506,30 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
         for (int mm = 0; mm < 8 * C; ++mm) perm[mm] = ((mm % 64) / 32 == 0 ? 0 : 4 * C) + 32 * (mm / 64) + mm % 32;
         if (!pack_ln_fold(o, f1, f1b, lg[2], lb[2], 8 * C, C, perm, t.ff1, t.ff1_c1, t.ff1_c2)) return false;
     }
-    if (!pack_conv(o, f2, f2b, C, 4 * C, 1, t.ff2)) return false;
+    {
+        // ff.net.2 (4C -> C, + residual h) and proj_out (C -> C, + residual x) are two linear maps with nothing between them
+        // (reference attention.py:197-203, transformer_1d.py:289-295):
+        //   out = Wp (W2 ff + b2 + h) + bp + x = [Wp W2 | Wp] [ff ; h] + (Wp b2 + bp) + x
+        // so they run as ONE convolution over the virtual concat [ff ; h] (5C input channels) with host-composed weights
+        // (products accumulated in double, rounded to fp32 once): same FLOPs, one launch and one activation round trip fewer.
+        const int C4 = 4 * C, C5 = 5 * C;
+        std::vector<float> wcat((size_t)C * C5), bcat(C);
+        std::vector<double> acc(C4);
+        for (int m = 0; m < C; ++m) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            double bs = (double)pob[m];
+            for (int k = 0; k < C; ++k) {
+                const double a = (double)pow_[(size_t)m * C + k];
+                const float* w2r = f2 + (size_t)k * C4;
+                for (int n = 0; n < C4; ++n) acc[n] += a * (double)w2r[n];
+                bs += a * (double)f2b[k];
+                wcat[(size_t)m * C5 + C4 + k] = pow_[(size_t)m * C + k];
+            }
+            for (int n = 0; n < C4; ++n) wcat[(size_t)m * C5 + n] = (float)acc[n];
+            bcat[m] = (float)bs;
+        }
+        if (!pack_conv(o, wcat.data(), bcat.data(), C, C5, 1, t.ff2_out)) return false;
+    }
     return true;
 }
 
@@ -525,9 +548,10 @@ extern "C" int lds_unet_create(const lds_unet_cfg* cfg, int n, const char* const
     u->temb = boc[0] * 4;
     for (int i = 0; i < nb; ++i) {
         const int hd = boc[i] / cfg->n_heads;
-        if (boc[i] % 64 != 0 || boc[i] % cfg->norm_groups != 0 || (hd != 32 && hd != 48 && hd != 64)) {
+        // 16 * groups: GroupNorm statistics travel as 16-channel partials, and a skip-concat's groups must be made of whole ones
+        if (boc[i] % 64 != 0 || cfg->norm_groups <= 0 || boc[i] % (16 * cfg->norm_groups) != 0 || (hd != 32 && hd != 48 && hd != 64)) {
             delete u;
-            return fail(LDS_EINVAL, "block_out_channels[%d]=%d unsupported (need multiple of 64, head dim 32/48/64)", i, boc[i]);
+            return fail(LDS_EINVAL, "block_out_channels[%d]=%d unsupported (need a multiple of 64 and of 16*norm_groups, head dim 32/48/64)", i, boc[i]);
         }
     }
     if ((u->M % 16) || (u->H % 16)) { delete u; return fail(LDS_EINVAL, "out_dims and n_hidden must be multiples of 16"); }
@@ -778,12 +802,9 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     of.epi = EPI_GEGLU;
     of.ln_part = w.lnp; of.ln_np = C / 32; of.ln_c1 = t.ff1_c1; of.ln_c2 = t.ff1_c2;
     LDS_TRY(run_dconv(t.ff1, h, C, nullptr, 0, T, of, w.ff, B, st));
-    DOpt o2;
-    o2.res = h;
-    LDS_TRY(run_dconv(t.ff2, w.ff, 4 * C, nullptr, 0, T, o2, hn, B, st));
-    DOpt o3;
-    o3.res = x; o3.gnpart_out = w.gp(out);
-    return run_dconv(t.proj_out, hn, C, nullptr, 0, T, o3, out, B, st);
+    DOpt o2;      // ff.net.2 + residual + proj_out + residual in one launch (load_tfm: ff2_out)
+    o2.res = x; o2.gnpart_out = w.gp(out);
+    return run_dconv(t.ff2_out, w.ff, 4 * C, h, C, T, o2, out, B, st);
 }
 
 // uniform_t: every batch element shares t[0] (the samplers' case) -> the time-embedding path runs for one column and
@@ -1426,6 +1447,41 @@ extern "C" int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C
     HIP_TRY(launch_gn_stream(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (const float2*)p1, (const float2*)p2, ky, B, st));
     HIP_TRY(launch_from_k4p(ky, out, B, C, T, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
+// timing of the streaming GroupNorm alone on zero-filled tensors (tools/bench_gn.py)
+extern "C" int lds_bench_gn_stream(int C1, int C2, int T, int B, int iters, float* ms_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TmpDev tmp;
+    const int C = C1 + C2, nT = (T + 31) / 32;
+    float* k1 = tmp.f((size_t)B * C1 * (T + 2));
+    float* k2 = C2 ? tmp.f((size_t)B * C2 * (T + 2)) : nullptr;
+    float* ky = tmp.f((size_t)B * C * (T + 2));
+    float* p1 = tmp.f((size_t)B * (C1 / 16) * nT * 2);
+    float* p2 = C2 ? tmp.f((size_t)B * (C2 / 16) * nT * 2) : nullptr;
+    float* gb = tmp.f(2 * C);
+    if (!k1 || (C2 && (!k2 || !p2)) || !ky || !p1 || !gb || iters <= 0 || !ms_out) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(hipMemsetAsync(k1, 0, sizeof(float) * B * C1 * (T + 2), st));
+    if (C2) HIP_TRY(hipMemsetAsync(k2, 0, sizeof(float) * B * C2 * (T + 2), st));
+    HIP_TRY(hipMemsetAsync(gb, 0, sizeof(float) * 2 * C, st));
+    HIP_TRY(launch_gn_partials(k1, C1, T, (float2*)p1, B, st));
+    if (C2) HIP_TRY(launch_gn_partials(k2, C2, T, (float2*)p2, B, st));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int w = 0; w < 3; ++w)
+        HIP_TRY(launch_gn_stream(k1, k2, C1, C2, T, 8, 1e-5f, gb, gb + C, nullptr, 0, 0, 1, (const float2*)p1, (const float2*)p2, ky, B, st));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(launch_gn_stream(k1, k2, C1, C2, T, 8, 1e-5f, gb, gb + C, nullptr, 0, 0, 1, (const float2*)p1, (const float2*)p2, ky, B, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return LDS_OK;
 }
 

@@ -44,7 +44,7 @@ EXPORTS = [
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
-    "lds_test_gn_apply", "lds_test_gn_chain_k4p", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
+    "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
     "lds_test_conv_transpose"]
 
 

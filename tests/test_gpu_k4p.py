@@ -169,12 +169,13 @@ def test_conv_dma_layernorm_partials(cfg):
     assert np.abs(ln[..., 1] - ((t - t.mean(2, keepdims=True)) ** 2).sum(2)).max() < 1e-3
 
 
-@pytest.mark.parametrize("C1,C2,T,silu,ss", [(64, 0, 64, 1, False), (80, 176, 50, 1, False), (128, 0, 64, 1, True), (256, 0, 37, 0, False),
-                                             (512, 384, 128, 1, False),
-                                             (256, 256, 512, 1, True),      # 9 register entries per thread (largest model shape)
-                                             (512, 0, 700, 1, False),       # 12 entries per thread
-                                             (64, 64, 3000, 1, True)])      # group too large for one workgroup: gn_part + gn_apply
+@pytest.mark.parametrize("C1,C2,T,silu,ss", [(128, 0, 64, 1, False), (80, 176, 50, 1, False), (128, 0, 64, 1, True), (256, 0, 37, 0, False),
+                                             (512, 384, 128, 1, False),     # 112-channel groups straddle the two sources
+                                             (256, 256, 512, 1, True),      # largest model shape: 64 partials per group
+                                             (512, 0, 700, 1, False),       # more than one chunk per workgroup, ragged last frame block
+                                             (64, 64, 3000, 1, True)])      # 94 partials per group, six chunks
 def test_gn_apply(C1, C2, T, silu, ss):
+    """streaming GroupNorm (gn_stream) fed by stand-alone partial statistics (gn_partials)"""
     from lds import native
     from oracle import unet1d
     B, C = 2, C1 + C2
@@ -195,6 +196,32 @@ def test_gn_apply(C1, C2, T, silu, ss):
     if silu:
         ref = unet1d.silu(ref)
     assert relmax(out.cpu().numpy(), ref) < 1e-5, relmax(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("C,Co,T,B,cfg,silu", [(64, 256, 70, 2, 0, 1), (128, 512, 37, 1, 32064322, 0), (64, 384, 100, 2, 128064322, 1),
+                                               (64, 256, 512, 2, 128128162, 1), (256, 384, 256, 1, 64064163, 1), (64, 128, 33, 3, 0, 1)])
+def test_groupnorm_chain_k4p(C, Co, T, B, cfg, silu):
+    """the UNet's GroupNorm statistics path: the producing convolution's epilogue writes (mean, M2) of every (16 channels x
+    32 frames) block -- from every tile shape, the split-K one included -- and gn_stream combines them"""
+    from lds import native
+    from oracle import unet1d
+    x = U(f"gnc{C}.{T}.x", (B, C, T), -2, 2)
+    w1 = (U(f"gnc{C}.{T}.w1", (Co, C)) / np.float32(np.sqrt(C))).astype(np.float32)
+    b1 = U(f"gnc{C}.{T}.b1", (Co,), 0.5, 1.5)                                      # a mean well away from zero
+    g, be = U(f"gnc{C}.{T}.g", (Co,), 0.5, 1.5), U(f"gnc{C}.{T}.b", (Co,), -0.5, 0.5)
+    mid = torch.full((B, Co, T), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.full((B, Co, T), float("nan"), dtype=torch.float32, device="cuda")
+    dx = dev(x)
+    native.check(native.lib().lds_test_gn_chain_k4p(ct.c_void_p(dx.data_ptr()), ct.c_void_p(w1.ctypes.data), ct.c_void_p(b1.ctypes.data),
+                                                    ct.c_void_p(g.ctypes.data), ct.c_void_p(be.ctypes.data), ct.c_float(1e-5), 8, silu,
+                                                    ct.c_void_p(mid.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, Co, T, cfg, stream()))
+    torch.cuda.synchronize()
+    rmid = unet1d.conv1d(x, w1[:, :, None], b1)
+    ref = unet1d.group_norm(rmid, g, be, 8, 1e-5)
+    if silu:
+        ref = unet1d.silu(ref)
+    assert relmax(mid.cpu().numpy(), rmid) < 2e-5
+    assert relmax(out.cpu().numpy(), ref) < 2e-5, relmax(out.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("C,Co,T,B", [(256, 768, 64, 2), (384, 384, 100, 1), (512, 1536, 37, 2)])
