@@ -103,6 +103,13 @@ int lds_embed_forward(lds_embed* e, const float* units, const int64_t* spk_id, f
 /* out[b,c,r] = in[b,r,c] / div  (the [B,T,M] <-> [B,M,T] layout changes at the module
  * boundary: reference diffusion/diffusion.py:190,342-343, hifi_vaegan.py:54). */
 int lds_transpose(const float* in, float* out, int B, int R, int C, float div, void* stream);
+/* ---- token -> unit-embedding step in front of the path (reference 22_infer_tts.py:43-52,100-110) -------------
+ * out[i,:] = table[idx[i],:]: the k-means codebook lookup `semantic_embedding(semantic_token)` (nn.Embedding over
+ * cluster_centers_ [n_rows, C]); an index outside [0, n_rows) yields a NaN row (nn.Embedding raises). */
+int lds_gather_rows(const float* table, const int64_t* idx, float* out, int n_idx, int C, int n_rows, void* stream);
+/* out[b,i,:] = in[b, min((int)floorf(i*step), Tin-1), :]: F.interpolate(mode='nearest') of units_forced_alignment
+ * (reference tools/tools.py:193-223) on frame-major units [B,Tin,C] -> [B,Tout,C]; step = 1/scale_factor (fp32). */
+int lds_resample_frames(const float* in, float* out, int B, int Tin, int Tout, int C, float step, void* stream);
 /* out = c0*a + c1*b over n elements (q_sample of shallow diffusion, reference diffusion.py:169-171) */
 int lds_axpby(float* out, const float* a, const float* b, float c0, float c1, int64_t n, void* stream);
 

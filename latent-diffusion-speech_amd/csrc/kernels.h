@@ -133,6 +133,7 @@ hipError_t launch_fill(float* p, float v, long long n, hipStream_t s);
 hipError_t launch_transpose(const float* in, float* out, int B, int R, int C, float scale, hipStream_t s);
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, int idx_off, float* out, int B, int C,
                               int nrows, hipStream_t s);
+hipError_t launch_resample_frames(const float* in, float* out, int B, int Tin, int Tout, int C, float step, hipStream_t s);
 hipError_t launch_resample_nearest(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
 
 

@@ -163,6 +163,22 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, int idx_of
     return hipGetLastError();
 }
 
+// nearest resampling of frame-major rows: out[b, i, :] = in[b, min((int)floorf(i * step), Tin - 1), :]
+// (F.interpolate(mode='nearest') on [B,C,T] seen from the [B,T,C] side: reference tools/tools.py:205-214)
+__global__ void resample_frames_kernel(const float* __restrict__ in, float* __restrict__ out, int Tin, int Tout, int C, float step) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    int src = (int)floorf((float)i * step);
+    if (src > Tin - 1) src = Tin - 1;
+    const float* ib = in + ((long long)b * Tin + src) * C;
+    float* ob = out + ((long long)b * Tout + i) * C;
+    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) ob[cc] = ib[cc];
+}
+hipError_t launch_resample_frames(const float* in, float* out, int B, int Tin, int Tout, int C, float step, hipStream_t s) {
+    if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resample_frames_kernel, dim3(Tout, B), dim3(256), 0, s, in, out, Tin, Tout, C, step);
+    return hipGetLastError();
+}
+
 // F.interpolate(mode='nearest', size=Tout): src = min(int(floor(dst * (float)Tin/Tout)), Tin-1)
 __global__ void __launch_bounds__(256) resample_nearest_kernel(const float* __restrict__ in, float* __restrict__ out, int Tin, int Tout, long long rows) {
     const float sc = (float)Tin / (float)Tout;

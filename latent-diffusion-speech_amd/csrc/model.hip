@@ -1127,6 +1127,18 @@ extern "C" int lds_transpose(const float* in, float* out, int B, int R, int C, f
     return LDS_OK;
 }
 
+extern "C" int lds_gather_rows(const float* table, const int64_t* idx, float* out, int n_idx, int C, int n_rows, void* stream) {
+    if (!table || !idx || !out || n_idx <= 0 || C <= 0 || n_rows <= 0) return fail(LDS_EINVAL, "bad argument");
+    HIP_TRY(launch_gather_rows(table, idx, 0, out, n_idx, C, n_rows, (hipStream_t)stream));
+    return LDS_OK;
+}
+
+extern "C" int lds_resample_frames(const float* in, float* out, int B, int Tin, int Tout, int C, float step, void* stream) {
+    if (!in || !out) return fail(LDS_EINVAL, "bad argument");
+    HIP_TRY(launch_resample_frames(in, out, B, Tin, Tout, C, step, (hipStream_t)stream));
+    return LDS_OK;
+}
+
 extern "C" int lds_axpby(float* out, const float* a, const float* b, float c0, float c1, int64_t n, void* stream) {
     if (!out || !a || !b || n <= 0) return fail(LDS_EINVAL, "bad argument");
     HIP_TRY(launch_ew(EW_AXPBY, out, a, b, nullptr, nullptr, c0, -c1, 0, 0, 0, n, (hipStream_t)stream));

@@ -42,7 +42,7 @@ class DConvTest(C.Structure):
 EXPORTS = [
     "lds_last_error", "lds_version", "lds_unet_create", "lds_unet_destroy", "lds_unet_workspace_bytes",
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
-    "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
+    "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_gather_rows", "lds_resample_frames", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
     "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
     "lds_test_conv_transpose"]
@@ -220,6 +220,27 @@ def axpby(a, b, c0, c1):
     out = torch.empty_like(a)
     check(lib().lds_axpby(_dev(out), _dev(a, torch.float32), _dev(b, torch.float32), C.c_float(c0), C.c_float(c1),
                           C.c_int64(a.numel()), _stream()))
+    return out
+
+
+def gather_rows(table, idx):
+    """table [N, C] fp32, idx int64 [...] -> table[idx] [..., C] on the device (codebook lookup)."""
+    import torch
+    idx = idx.contiguous()
+    N, Cc = table.shape
+    out = torch.empty(tuple(idx.shape) + (Cc,), dtype=torch.float32, device=table.device)
+    if idx.numel():
+        check(lib().lds_gather_rows(_dev(table, torch.float32), _dev(idx, torch.int64), _dev(out), idx.numel(), Cc, N, _stream()))
+    return out
+
+
+def resample_frames(x, n_out, step):
+    """x [B, T, C] -> [B, n_out, C]: out[:, i] = x[:, min(floor(i * step), T - 1)] (nearest, fp32 index arithmetic)."""
+    import torch
+    B, T, Cc = x.shape
+    out = torch.empty(B, n_out, Cc, dtype=torch.float32, device=x.device)
+    if n_out:
+        check(lib().lds_resample_frames(_dev(x, torch.float32), _dev(out), B, T, n_out, Cc, C.c_float(step), _stream()))
     return out
 
 

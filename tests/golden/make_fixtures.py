@@ -13,6 +13,8 @@ reference.  Writes small .npz/.json files (default: next to this script, `--out 
                       method with k_step != 1000: outputs stay O(1), DDPM without clamp saturation
   vocoder.npz         Generator forward (synthetic h), weight-norm checkpoint
   vocoder_rb2.npz     Generator forward with resblock '2' (reference models.py:201-222)
+  units_align.npz     units_forced_alignment (reference tools/tools.py:193-223): nearest by scale factor / by size, 'left'
+  resume.json         which checkpoint tools/utils.py:load_model restores from a directory of model_<step>.pt files
 
 Weights always come from the build-owned seeded initialiser (lds/init_weights.py) loaded
 into the reference modules with load_state_dict, so they can be regenerated anywhere.
@@ -63,27 +65,50 @@ torch.set_num_threads(8)
 
 # import-only placeholders for packages the container lacks; the decoder
 # classes we run never touch them.
-_vq = types.ModuleType("vector_quantize_pytorch")
-_vq.VectorQuantize = object
-sys.modules.setdefault("vector_quantize_pytorch", _vq)
-_ta = types.ModuleType("torchaudio")
-_tat = types.ModuleType("torchaudio.transforms")
-_ta.transforms = _tat
-for n in ("Spectrogram", "Resample", "MelSpectrogram"):
-    setattr(_tat, n, object)
-sys.modules.setdefault("torchaudio", _ta)
-sys.modules.setdefault("torchaudio.transforms", _tat)
+def _placeholder(name, **attrs):
+    """an import-only stand-in module (with a spec, so importlib.util.find_spec accepts it)"""
+    import importlib.machinery
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return sys.modules.setdefault(name, m)
+
+
+_placeholder("vector_quantize_pytorch", VectorQuantize=object)
+_tat = _placeholder("torchaudio.transforms", Spectrogram=object, Resample=object, MelSpectrogram=object)
+_placeholder("torchaudio", transforms=_tat)
 
 from diffusion.diffusion import GaussianDiffusion  # noqa: E402  (reference)
 from diffusion.unet1d.unet_1d_condition import UNet1DConditionModel  # noqa: E402
 from diffusion import dpm_solver_pytorch, uni_pc  # noqa: E402
 from encoder.hifi_vaegan.modules.models import Generator  # noqa: E402
+from tools import utils as ref_utils  # noqa: E402
+
+
+def _reference_function(rel_path, name):
+    """One top-level function of a reference module whose module-level imports cannot be satisfied here (tools/tools.py
+    pulls librosa / fairseq / torchaudio-backed transformers classes for its speech encoders): the function's own source is
+    compiled from the reference file (same file name and line numbers) and run with torch / numpy in scope."""
+    import ast
+    file = os.path.join(REF, rel_path)
+    tree = ast.parse(open(file).read(), filename=file)
+    node = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(node) == 1, (rel_path, name)
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=node, type_ignores=[]), file, "exec"), ns)
+    return ns[name]
+
+
+class ref_tools:  # noqa: N801
+    units_forced_alignment = staticmethod(_reference_function("tools/tools.py", "units_forced_alignment"))
 
 
 def reference_origin():
     """name -> source file of every reference object the fixtures are produced with"""
     objs = {"GaussianDiffusion": GaussianDiffusion, "UNet1DConditionModel": UNet1DConditionModel,
-            "dpm_solver_pytorch": dpm_solver_pytorch, "uni_pc": uni_pc, "Generator": Generator}
+            "dpm_solver_pytorch": dpm_solver_pytorch, "uni_pc": uni_pc, "Generator": Generator,
+            "units_forced_alignment": ref_tools.units_forced_alignment, "load_model": ref_utils.load_model}
     return {k: os.path.realpath(inspect.getfile(v)) for k, v in objs.items()}
 
 
@@ -306,6 +331,53 @@ def main():
     print("vocoder rb2", wav2.shape, float(np.abs(wav2).max()))
     np.savez_compressed(path("vocoder_rb2.npz"), z=z2, wav=wav2,
                         h_json=np.frombuffer(json.dumps(h2, sort_keys=True).encode(), dtype=np.uint8))
+
+    # ---------------- token -> unit step: forced alignment of unit frames -------------
+    ua = {}
+    u = init_weights.uniform("fix.align.units", (2, 37, 64), 16, -1.0, 1.0)
+    sf = (44100 / 512) / (16000 / 320)                    # 22_infer_tts.py:108-110
+    ua["units"] = u
+    ua["scale_factor"] = np.float64(sf)
+    # reachable call patterns of the reference function: target length given (size), audio + hop given, 'left' gather
+    ua["nearest_size50"] = ref_tools.units_forced_alignment(tt(u), n_frames=50).numpy()
+    ua["nearest_size64_2d"] = ref_tools.units_forced_alignment(tt(u[0]), n_frames=64).numpy()
+    ua["nearest_audio"] = ref_tools.units_forced_alignment(tt(u), audio=torch.zeros(1, 512 * 45 + 17), sample_rate=44100, hop_size=512).numpy()
+    ua["left_60"] = ref_tools.units_forced_alignment(tt(u[:1]), n_frames=60, scale_factor=1.0 / sf, units_forced_mode="left").numpy()
+    # 22_infer_tts.py:108-110 passes scale_factor ONLY; the reference function then dereferences audio=None (tools.py:195) and
+    # raises before reaching its F.interpolate(..., scale_factor=sf, mode='nearest') line.  The expected outputs of that
+    # intended call are produced with the same torch call the function would make (tools.py:212-214).
+    try:
+        ref_tools.units_forced_alignment(tt(u), scale_factor=sf)
+        ua["scale_only_raises"] = np.array(0)
+    except AttributeError:
+        ua["scale_only_raises"] = np.array(1)
+    for tag, f in (("nearest_sf", sf), ("nearest_sf_down", 1.0 / sf)):
+        ua[tag] = torch.nn.functional.interpolate(tt(u).transpose(-1, -2), size=None, scale_factor=f, mode="nearest").transpose(-1, -2).contiguous().numpy()
+    print("units_forced_alignment", {k: v.shape for k, v in ua.items() if hasattr(v, "shape")})
+    np.savez_compressed(path("units_align.npz"), **ua)
+
+    # ---------------- resume-from-highest-step ---------------------------------------
+    import tempfile
+    cases = {"plain": ["model_100.pt", "model_2000.pt", "model_300.pt"], "with_best": ["model_7.pt", "model_best.pt"],
+             "only_best": ["model_best.pt"], "other_files": ["model_40.pt", "notes.txt", "model_5.pt"], "empty": []}
+    picked = {}
+    for cname, files in cases.items():
+        with tempfile.TemporaryDirectory() as d:
+            for f in files:
+                if f.endswith(".pt"):
+                    stem = f[len("model_"):-3]
+                    torch.save({"global_step": int(stem) if stem.isdigit() else -1, "model": {"w": torch.tensor([float(len(stem))])}}, os.path.join(d, f))
+                else:
+                    open(os.path.join(d, f), "w").write("x")
+            lin = torch.nn.Module()
+            lin.w = torch.nn.Parameter(torch.zeros(1))
+            try:
+                step, _, _ = ref_utils.load_model(d, lin, None)
+                picked[cname] = {"files": files, "global_step": int(step), "w": float(lin.w.item())}
+            except Exception as e:       # e.g. model_0.pt missing when only model_best.pt exists
+                picked[cname] = {"files": files, "raises": type(e).__name__}
+    print("resume", picked)
+    json.dump(picked, open(path("resume.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
