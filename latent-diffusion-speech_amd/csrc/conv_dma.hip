@@ -61,7 +61,7 @@ static __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1>
 struct DmaCfg {
     // BM = 32: split-K inside the workgroup for grids smaller than the chip.  The tile is 32 x 64; waves (wn, ks) take
     // column block wn and half ks of every K-step's k range, and the two partial sums meet through LDS in the epilogue
@@ -69,7 +69,7 @@ struct DmaCfg {
     static constexpr bool SPLIT = BM == 32;
     static constexpr int TM = SPLIT ? 1 : BM / 64, TN = BN / 64;
     static constexpr int KR = BK / 4;                                   // staged k-rows per K-step
-    static constexpr int XW = UPS ? (BN / 2 + 2) : ((BN - 1) * STRIDE + KT);   // window entries (frames) per k-row
+    static constexpr int XW = UPS ? (BN / 2 + 2) : ((BN - 1) * STRIDE + (KT - 1) * DIL + 1);   // window entries (frames) per k-row; taps are DIL entries apart
     static constexpr int WI = KT * KR * BM / 64;                        // weight DMA wave-instructions per tile
     static constexpr int WPW = WI / 4;                                  // ... per wave
     static constexpr int RPW = KR / 4;                                  // activation k-rows staged by each wave
@@ -88,9 +88,9 @@ struct DmaCfg {
     static_assert(!SPLIT || (BN == 64 && BK % 16 == 0), "split-K tile is 32 x 64");
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
 struct DmaKernel {
-    using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>;
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, KR = Cfg::KR, XW = Cfg::XW, WPW = Cfg::WPW, RPW = Cfg::RPW, NXI = Cfg::NXI;
     static constexpr int G = Cfg::G, NB = Cfg::NB, NACC = Cfg::NACC, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE, KQW = Cfg::KQW;
     static constexpr bool SPLIT = Cfg::SPLIT;
@@ -145,8 +145,8 @@ struct DmaKernel {
             const int rr = rem / BM, m = rem - rr * BM;
             woff[i] = ((tap * (p.Ci / 4) + rr) * p.Mp + m0 + m) * 16;
         }
-        const int Tp = p.Tsrc + 2;
-        const int e0 = UPS ? (((t0 - 1) >> 1) + 1) : (t0 * STRIDE - p.pad + 1);   // first window entry (pad frame = entry 0)
+        const int Tp = p.Tsrc + 2 * p.xpad;
+        const int e0 = UPS ? (((t0 - 1) >> 1) + p.xpad) : (t0 * STRIDE - p.pad + p.xpad);   // first window entry (entry xpad = frame 0)
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
             const int qq = i * 64 + lane;
@@ -180,7 +180,7 @@ struct DmaKernel {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + ((wave + 4 * i) * 64) * 4), 16, woff[i], ws, 0, 0);
         const int k0 = kc * BK;
         const bool s2 = k0 >= p.C1;                              // C1 % BK == 0: a K-step reads one source only
-        const int xsoff = (s2 ? k0 - p.C1 : k0) * (p.Tsrc + 2) * 4;
+        const int xsoff = (s2 ? k0 - p.C1 : k0) * (p.Tsrc + 2 * p.xpad) * 4;
         float* xs = st + KT * BK * BM + wave * RPW * XW * 4;
 #pragma unroll
         for (int i = 0; i < NXI; ++i)
@@ -198,7 +198,7 @@ struct DmaKernel {
         for (int i = 0; i < TM; ++i) aop[SLOT][i] = *reinterpret_cast<const f32x4*>(wt + i * 32 * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - ((t0 - 1) >> 1)) : (bcol[j] * STRIDE + tap);
+            const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - ((t0 - 1) >> 1)) : (bcol[j] * STRIDE + tap * DIL);
             bop[SLOT][j] = *reinterpret_cast<const f32x4*>(xs + col * 4);
         }
     }
@@ -292,14 +292,14 @@ struct DmaKernel {
     }
 
     __device__ __forceinline__ bool res_tile(int tile0, int n) const {
-        return p.res && !p.out_plain && tile0 < p.plain_from && tile0 < p.Cout && n < p.To;
+        return p.res && tile0 < p.plain_from && tile0 < p.Cout && n < p.To;      // the residual is always a K4P tensor
     }
     __device__ __forceinline__ void early_loads() {
         const int tile0 = m0 + wm * TM * 32, n = t0 + wn * TN * 32 + c;
 #pragma unroll
         for (int e = 0; e < 8; ++e) rsv[e] = f32x2{0.f, 0.f};
         if (res_tile(tile0, n)) {
-            const int Tpo = p.To + 2;
+            const int Tpo = p.To + 2 * p.opad;
             const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) rsv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
@@ -374,11 +374,30 @@ struct DmaKernel {
     // frame-major store of one 32x32 tile: out[b][co][n], co = c0 + local row
     __device__ __forceinline__ void store_plain(float* base, int Cn, int c0, int i, int j, int n) {
         if (n >= p.To) return;
+        if (VOC && p.acc_in) {                 // MRF running sum kept in K4P (same channels / frames / padding as a K4P output would have)
+            const int Tpo = p.To + 2 * p.opad;
+            const float* ab = p.acc_in + (long long)b * Cn * Tpo + k4p_off(c0, n);
+            f32x2 av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const f32x2*>(ab + e * Tpo * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    acc[0][i][j][4 * g + hh] += av[2 * g + hh][0];
+                    acc[0][i][j][4 * g + 2 + hh] += av[2 * g + hh][1];
+                }
+        }
         float* ob = base + ((long long)b * Cn + c0) * p.To + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (c0 + rl < Cn) ob[rl * p.To] = acc[0][i][j][r];
+            float v = acc[0][i][j][r];
+            if constexpr (VOC) {
+                if (p.out_div != 1.0f) v = v / p.out_div;
+                if (p.act_slope != 0.f) v = (v >= 0.f) ? v : v * p.act_slope;
+            }
+            if (c0 + rl < Cn) ob[rl * p.To] = v;
         }
     }
 
@@ -402,7 +421,7 @@ struct DmaKernel {
     // K4P addressing of one 32x32 tile.  Registers (4g+hh, 4g+2+hh) of this lane are elements (2h, 2h+1) of row
     // (q = tile0/8 + g, hh): two 8-byte accesses per 8-channel block; the two lane halves together fill the 16-byte entry,
     // and consecutive lanes are consecutive frames.
-    __device__ __forceinline__ int k4p_off(int tile0, int n) const { return (((tile0 >> 3) * 2) * (p.To + 2) + n + 1) * 4 + 2 * h; }
+    __device__ __forceinline__ int k4p_off(int tile0, int n) const { return (((tile0 >> 3) * 2) * (p.To + 2 * p.opad) + n + p.opad) * 4 + 2 * h; }
     __device__ __forceinline__ int k4p_ck() const { return (p.plain_from < p.Cout) ? p.plain_from : p.Cout; }
 
     // phase 2: residual add (all loads in flight together, before any store)
@@ -413,7 +432,7 @@ struct DmaKernel {
 #pragma unroll
             for (int e = 0; e < 8; ++e) rv[e] = rsv[e];
         } else {
-            const int Tpo = p.To + 2;
+            const int Tpo = p.To + 2 * p.opad;
             const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) rv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
@@ -427,25 +446,59 @@ struct DmaKernel {
             }
     }
 
-    // phase 3: K4P store of one 32x32 tile (+ pad frames, + LayerNorm partials)
+    // phase 3: K4P store of one 32x32 tile (+ pad frames, + GroupNorm / LayerNorm partials).  Vocoder epilogues: the running
+    // sum of the MRF (acc_in, out_div), LeakyReLU of the value for the next convolution (act_slope; out_act = second tensor
+    // when the raw value is needed too, as a residual).
     __device__ __forceinline__ void store_k4p(int tile0, int i, int j, int n) {
-        const int Tpo = p.To + 2;
+        const int Tpo = p.To + 2 * p.opad;
         const int Ck = k4p_ck();
         const bool ok = n < p.To;
-        float* ob = p.out + (long long)b * Ck * Tpo + k4p_off(tile0, n);
+        const long long o0 = (long long)b * Ck * Tpo + k4p_off(tile0, n);
+        float* ob = p.out + o0;
         if (ok) {
+            if constexpr (VOC) {
+            if (p.acc_in) {
+                f32x2 av[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const f32x2*>(p.acc_in + o0 + e * Tpo * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        acc[0][i][j][4 * g + hh] += av[2 * g + hh][0];
+                        acc[0][i][j][4 * g + 2 + hh] += av[2 * g + hh][1];
+                    }
+            }
+            if (p.out_div != 1.0f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
+            }
+            if (p.act_slope != 0.f && p.out_act) {      // raw value to `out`, activated value to `out_act`
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) k4p_store_wt(ob + (2 * g + hh) * Tpo * 4, f32x2{acc[0][i][j][4 * g + hh], acc[0][i][j][4 * g + 2 + hh]});
+                ob = p.out_act + o0;
+            }
+            if (p.act_slope != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[0][i][j][r]; acc[0][i][j][r] = (v >= 0.f) ? v : v * p.act_slope; }
+            }
+            }      // VOC
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
                     k4p_store_wt(ob + (2 * g + hh) * Tpo * 4, f32x2{acc[0][i][j][4 * g + hh], acc[0][i][j][4 * g + 2 + hh]});
-            if (n == 0) {                     // left pad frame
+            if (p.opad == 1) {                    // one pad frame per side is written with the tensor; wider pads are zeroed by k4p_zero_pads
+                if (n == 0) {                     // left pad frame
 #pragma unroll
-                for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 - 4) = f32x2{0.f, 0.f};
-            }
-            if (n == p.To - 1) {              // right pad frame
+                    for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 - 4) = f32x2{0.f, 0.f};
+                }
+                if (n == p.To - 1) {              // right pad frame
 #pragma unroll
-                for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 + 4) = f32x2{0.f, 0.f};
+                    for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(ob + e * Tpo * 4 + 4) = f32x2{0.f, 0.f};
+                }
             }
         }
         if (p.gnpart_out) {
@@ -526,7 +579,7 @@ struct DmaKernel {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int tile0 = tile_ch(i, geglu);
-                    if (!p.out_plain && tile0 < p.plain_from && tile0 < p.Cout) add_residual(tile0, i, j, t0 + wn * TN * 32 + j * 32 + c);
+                    if (tile0 < p.plain_from && tile0 < p.Cout) add_residual(tile0, i, j, t0 + wn * TN * 32 + j * 32 + c);
                 }
             }
         }
@@ -548,10 +601,10 @@ struct DmaKernel {
     }
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
-__global__ void __launch_bounds__(256, (DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>::OCC)) conv_dma_kernel(const DmaConvArgs p) {
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
+__global__ void __launch_bounds__(256, (DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>::OCC)) conv_dma_kernel(const DmaConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST> k(p, smem);
+    DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC> k(p, smem);
     k.setup();
     k.mainloop();
     k.epilogue();
@@ -560,19 +613,19 @@ __global__ void __launch_bounds__(256, (DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>
 static thread_local char g_dcfg[96] = "";
 const char* conv_dma_last_config() { return g_dcfg; }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
 static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
-    using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>;
     const int nN = (a.To + BN - 1) / BN;
     dim3 grid((a.Mp / BM) * nN, a.B);
-    auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x,
-             grid.y, Cfg::LDS_BYTES);
+    if (!VOC) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x, grid.y, Cfg::LDS_BYTES);
+    else snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d D%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, DIL, grid.x, grid.y, Cfg::LDS_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 }
@@ -581,7 +634,17 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
 
 // cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
-    if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || (a.pad != 0 && a.pad != 1)) return hipErrorInvalidValue;
+    if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || a.xpad < 1 || a.opad < 1 || a.pad < 0 || a.pad > a.xpad) return hipErrorInvalidValue;
+    if (a.voc) {
+        // vocoder resblock convolutions (k 3 / 7 / 11, dilation 1 / 3 / 5; LeakyReLU / running-sum epilogues): one 64 x 128 tile shape,
+        // BK 16 (a K-step = 16 channels x all taps: 6 / 14 / 22 MFMA groups of 8 per wave), 2 stages (the weight tile of k 11 is 45 KB per stage)
+        if (a.stride != 1 || a.ups || a.epi != EPI_NONE || cfg != 0) return hipErrorInvalidValue;
+#define VCASE(KT_, D_) if (a.KT == KT_ && a.dil == D_) return launch_dma_cfg<64, 128, KT_, 1, false, 16, 2, D_, true>(a, s)
+        VCASE(3, 1); VCASE(3, 3); VCASE(3, 5); VCASE(7, 1); VCASE(7, 3); VCASE(7, 5); VCASE(11, 1); VCASE(11, 3); VCASE(11, 5);
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
+    if (a.dil != 1 || a.act_slope != 0.f || a.acc_in || a.out_div != 1.0f) return hipErrorInvalidValue;      // vocoder-only features
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     // The tile shape fixes the order of the K reduction, so it must not depend on the batch size: an utterance's result is then

@@ -38,6 +38,49 @@ hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int C
     return hipGetLastError();
 }
 
+// Vocoder entry into K4P: plain [B][C][T] -> K4P rows with `pad` zero frames per side (the dilated k 7 / 11 convolutions pad up to 25
+// frames), the raw tensor (residual operand) and its LeakyReLU (what the convolutions read: reference models.py:186-192 applies
+// F.leaky_relu before every conv, here once per tensor).  One workgroup per (8-channel block, 1024-frame slab, batch element).
+__global__ void __launch_bounds__(256) to_k4p_act_kernel(const float* __restrict__ in, float* __restrict__ raw, float* __restrict__ act,
+                                                         float slope, int C, int T, int pad) {
+    const int q = blockIdx.x, t0 = blockIdx.y * 1024, b = blockIdx.z;
+    const int Tp = T + 2 * pad;
+    const long long ro = (((long long)b * (C >> 3) + q) * 2) * Tp * 4;
+    const float* ib = in + ((long long)b * C + q * 8) * T;
+    for (int idx = threadIdx.x; idx < 2 * 1024; idx += 256) {
+        const int hh = idx >> 10, t = t0 + (idx & 1023);
+        if (t >= T) continue;
+        f32x4 v, a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = ib[(long long)(2 * j + hh) * T + t]; a[j] = (v[j] >= 0.f) ? v[j] : v[j] * slope; }
+        const long long o = ro + ((long long)hh * Tp + t + pad) * 4;
+        if (raw) *reinterpret_cast<f32x4*>(raw + o) = v;
+        if (act) *reinterpret_cast<f32x4*>(act + o) = a;
+    }
+}
+hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s) {
+    if ((C & 7) || pad < 1) return hipErrorInvalidValue;
+    ProfScope ps(s, "to_k4p_act", 0.0, 4.0 * B * (double)C * T * (1.0 + (raw ? 1.0 : 0.0) + (act ? 1.0 : 0.0)));
+    hipLaunchKernelGGL(to_k4p_act_kernel, dim3(C / 8, (T + 1023) / 1024, B), dim3(256), 0, s, in, raw, act, slope, C, T, pad);
+    return hipGetLastError();
+}
+
+// one workgroup per (b, 8-channel block): both rows' left and right pads
+__global__ void __launch_bounds__(256) k4p_zero_pads_kernel(float* __restrict__ x, int T, int pad) {
+    const int Tp = T + 2 * pad;
+    float* xb = x + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * Tp * 4;
+    for (int idx = threadIdx.x; idx < 4 * pad; idx += 256) {
+        const int hh = idx / (2 * pad), e = idx - hh * 2 * pad;
+        const int entry = (e < pad) ? e : T + e;                      // left pad entries 0..pad-1, right pad entries T+pad..T+2pad-1
+        *reinterpret_cast<f32x4*>(xb + ((long long)hh * Tp + entry) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+hipError_t launch_k4p_zero_pads(float* x, int B, int C, int T, int pad, hipStream_t s) {
+    if ((C & 7) || pad < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k4p_zero_pads_kernel, dim3(C / 8, B), dim3(256), 0, s, x, T, pad);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) from_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
     const int q = blockIdx.x, b = blockIdx.y;
     const int Tp = T + 2;

@@ -72,6 +72,14 @@ struct DmaConvArgs {
     // mean_t / rstd_t are combined per column from the producer's partials ln_part [B][ln_np][Tsrc]
     const float2* ln_part; int ln_np; float ln_eps; const float* ln_c1; const float* ln_c2;
     int Cout, To, B;
+    // vocoder extensions (HiFi-VAEGAN MRF, reference models.py:161-262); the UNet leaves them at dil 1, xpad = opad = 1, rest 0 / 1.0
+    int voc;                            // 1: vocoder kernel family (the fields below are honoured)
+    int dil;                            // tap spacing in frames (1, 3, 5)
+    int xpad, opad;                     // zero frames on each side of every K4P row of the inputs / of out, res, acc_in, out_act (>= pad)
+    float act_slope;                    // != 0: LeakyReLU(slope) of the final value is what the next convolution reads ...
+    float* out_act;                     // ... written here while `out` keeps the raw value (null: `out` receives the activated value)
+    const float* acc_in;                // K4P running sum added before the division: out = (acc_in + y) / out_div
+    float out_div;
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
@@ -98,6 +106,10 @@ hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, in
 // the same partials computed from a K4P tensor by a stand-alone pass (tensors not produced by conv_dma; test entry points)
 hipError_t launch_gn_partials(const float* x, int C, int T, float2* gp, int B, hipStream_t s);
 // nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
+// plain [B][C][T] -> K4P with `pad` zero frames per side: raw copy and (slope != 0) LeakyReLU copy (either output may be null)
+hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s);
+// zero the `pad` frames on both sides of every row of a K4P tensor (tensors whose writers only store real frames)
+hipError_t launch_k4p_zero_pads(float* x, int B, int C, int T, int pad, hipStream_t s);
 hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
 // self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v in the VT layout
 // [B][heads][ceil(T/4)][D][4] (key tail zeroed); out K4P [B][C][T]

@@ -347,6 +347,8 @@ struct DOpt {
     int vt_D = 0;
     float2* lnpart_out = nullptr;
     float2* gnpart_out = nullptr;
+    int voc = 0, dil = 1, xpad = 1, opad = 1;
+    float act_slope = 0.f; float* out_act = nullptr; const float* acc_in = nullptr; float out_div = 1.f;
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
 };
@@ -362,9 +364,10 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     a.Cout = (o.epi == EPI_GEGLU) ? W.Co / 2 : W.Co;
     a.plain_from = (o.plain_from >= 0) ? o.plain_from : a.Cout;
     a.out2 = o.out2; a.vt_D = o.vt_D; a.lnpart_out = o.lnpart_out; a.gnpart_out = o.gnpart_out;
+    a.voc = o.voc; a.dil = o.dil; a.xpad = o.xpad; a.opad = o.opad; a.act_slope = o.act_slope; a.out_act = o.out_act; a.acc_in = o.acc_in; a.out_div = o.out_div;
     a.ln_part = o.ln_part; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.ln_c1 = o.ln_c1; a.ln_c2 = o.ln_c2;
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
-    a.To = (Tin + 2 * o.pad - (W.K - 1) - 1) / o.stride + 1;
+    a.To = (Tin + 2 * o.pad - o.dil * (W.K - 1) - 1) / o.stride + 1;
     a.B = B;
     const double flops = 2.0 * B * (double)a.To * (double)W.Co * (double)W.Ci * (double)W.K;
     const double bytes = 4.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
@@ -377,7 +380,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
             std::string nm = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
             if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
                 char sh[96];
-                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "");
+                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "", o.acc_in ? " +acc" : "");
                 nm += sh;
             }
             ps.rename(nm);
@@ -1238,16 +1241,32 @@ extern "C" int lds_vocoder_create(const lds_vocoder_cfg* cfg, int n, const char*
 }
 extern "C" void lds_vocoder_destroy(lds_vocoder* v) { delete v; }
 
-struct VocWs { float *x, *xs, *ta, *ra, *rb; };
+// Stages whose width is a multiple of 64 run on the DMA-fed K4P kernel (conv_dma): the tensors between the resblock convolutions
+// live in K4P with kVocPad zero frames per side (the dilated k 7 / 11 taps reach 25 frames out), LeakyReLU is applied once per
+// tensor by the producer's epilogue, and the MRF's running sum is accumulated in K4P.  Narrower stages (the 32 / 16-channel
+// tail) and the transposed convolutions stay on the register-staged conv_gemm over plain tensors.
+constexpr int kVocPad = 32;
+struct VocWs { float *x, *xs, *ta, *ra, *rb; float *kx_raw, *kx_act, *kt_act, *ka_raw, *ka_act, *kb_raw, *kb_act, *ks; };
+static bool voc_dma_stage(const lds_vocoder* v, int ch) {
+    if (ch % 64) return false;
+    for (const VocRes& rb : v->rbs)
+        for (int d : rb.dil)
+            if ((rb.k * d - d) / 2 > kVocPad || (d != 1 && d != 3 && d != 5)) return false;
+    return true;
+}
 static void plan_voc(const lds_vocoder* v, Arena& A, int B, int T, VocWs& w) {
-    size_t mx = (size_t)v->cfg.upsample_initial_channel * T;
+    size_t mx = (size_t)v->cfg.upsample_initial_channel * T, mk = 0;
     int Tl = T;
     for (int i = 0; i < v->cfg.n_ups; ++i) {
         Tl *= v->cfg.upsample_rates[i];
-        const size_t ct = (size_t)(v->cfg.upsample_initial_channel >> (i + 1)) * Tl;
+        const int ch = v->cfg.upsample_initial_channel >> (i + 1);
+        const size_t ct = (size_t)ch * Tl;
         if (ct > mx) mx = ct;
+        if (voc_dma_stage(v, ch)) mk = std::max(mk, (size_t)ch * (Tl + 2 * kVocPad));
     }
     w.x = A.f(B * mx); w.xs = A.f(B * mx); w.ta = A.f(B * mx); w.ra = A.f(B * mx); w.rb = A.f(B * mx);
+    float** kb[8] = {&w.kx_raw, &w.kx_act, &w.kt_act, &w.ka_raw, &w.ka_act, &w.kb_raw, &w.kb_act, &w.ks};
+    for (float** pp : kb) *pp = mk ? A.f(B * mk + 4096) : nullptr;
 }
 extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out) {
     if (!v || !out || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
@@ -1258,9 +1277,55 @@ extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, s
     return LDS_OK;
 }
 
+// MRF of one stage on the K4P / LDS-DMA path (reference models.py:161-222,250-259): x plain [B][ch][Tl] -> xs plain = mean_j resblock_j(x)
+static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const float* x, float* xs, int ch, int Tl, int B, hipStream_t st) {
+    const lds_vocoder_cfg& c = v->cfg;
+    const int P = kVocPad;
+    HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kx_act, 0.1f, B, ch, Tl, P, st));
+    float* acts[4] = {w.kx_act, w.kt_act, w.ka_act, w.kb_act};
+    for (float* a : acts) HIP_TRY(launch_k4p_zero_pads(a, B, ch, Tl, P, st));      // the epilogues below store real frames only
+    for (int j = 0; j < c.n_kernels; ++j) {
+        const VocRes& rb = v->rbs[stage * c.n_kernels + j];
+        const float* cur_raw = w.kx_raw;
+        const float* cur_act = w.kx_act;
+        float* nraw[2] = {w.ka_raw, w.kb_raw};
+        float* nact[2] = {w.ka_act, w.kb_act};
+        const int nd = (int)rb.dil.size();
+        for (int m = 0; m < nd; ++m) {
+            const bool last = m == nd - 1;
+            const int d = rb.dil[m];
+            const float* in2 = cur_act;
+            DOpt o2;                                   // the convolution that closes the residual step: x = conv(...) + x
+            o2.voc = 1; o2.xpad = P; o2.opad = P; o2.res = cur_raw;
+            const ConvW* W2 = &rb.c1[m];
+            if (c.resblock == 1) {
+                DOpt o1;                               // xt = c1(lrelu(x)), stored as lrelu(xt)
+                o1.voc = 1; o1.xpad = P; o1.opad = P; o1.dil = d; o1.pad = (rb.k * d - d) / 2; o1.act_slope = 0.1f;
+                LDS_TRY(run_dconv(rb.c1[m], cur_act, ch, nullptr, 0, Tl, o1, w.kt_act, B, st));
+                in2 = w.kt_act; W2 = &rb.c2[m];
+                o2.pad = (rb.k - 1) / 2;
+            } else {
+                o2.dil = d; o2.pad = (rb.k * d - d) / 2;
+            }
+            float* dst;
+            if (!last) {                               // raw value (next residual) + LeakyReLU'd value (next convolution's input)
+                dst = nraw[m & 1]; o2.out_act = nact[m & 1]; o2.act_slope = 0.1f;
+            } else if (j < c.n_kernels - 1) {          // xs (+)= resblock_j(x), kept in K4P
+                dst = w.ks; o2.acc_in = (j > 0) ? w.ks : nullptr;
+            } else {                                   // xs = (xs + resblock_j(x)) / n_kernels, back in the plain layout
+                dst = xs; o2.out_plain = 1; o2.acc_in = (j > 0) ? w.ks : nullptr; o2.out_div = (float)c.n_kernels;
+            }
+            LDS_TRY(run_dconv(*W2, in2, ch, nullptr, 0, Tl, o2, dst, B, st));
+            cur_raw = nraw[m & 1]; cur_act = nact[m & 1];
+        }
+    }
+    return LDS_OK;
+}
+
 extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream) {
     if (!v || !z || !wav || !ws || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
+    ProfChain chain;
     Arena A(ws, ws_bytes);
     VocWs w;
     plan_voc(v, A, B, T, w);
@@ -1289,6 +1354,11 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
         }
         { float* t = x; x = xs; xs = t; }
         ch = cout; Tl = Tn;
+        if (voc_dma_stage(v, ch)) {
+            LDS_TRY(voc_mrf_dma(v, w, i, x, xs, ch, Tl, B, st));
+            { float* t = x; x = xs; xs = t; }
+            continue;
+        }
         for (int j = 0; j < c.n_kernels; ++j) {
             const VocRes& rb = v->rbs[i * c.n_kernels + j];
             const float* cur = x;
