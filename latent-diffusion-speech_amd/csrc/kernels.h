@@ -47,6 +47,12 @@ struct ConvArgs {
 hipError_t launch_conv_gemm(const ConvArgs& a, int tile, hipStream_t s);
 const char* conv_gemm_last_config();
 
+// conv_small (conv_small.hip): the vocoder's 16- / 32-channel resblock convolutions on v_mfma_f32_16x16x4_f32, weights resident in
+// registers, plain tensors.  Same ConvArgs semantics (LeakyReLU on the input, bias, residual, running sum, division).
+bool conv_small_applies(const ConvArgs& a);
+hipError_t launch_conv_small(const ConvArgs& a, hipStream_t s);
+const char* conv_small_last_config();
+
 // Weight packers (host side): reference layout -> [KT][Ci][Mp]
 size_t packed_conv_elems(int Co, int Ci, int K, int* Mp_out);
 
