@@ -221,3 +221,104 @@ def get_encoder_out_channels(encoder):
     if encoder in table:
         return table[encoder]
     raise ValueError(f"[x] Unknown encoder: {encoder}")
+
+
+# ---- text2semantic RoFormer (reference text2semantic/roformer/roformer.py:8-160; HF transformers RoFormerModel /
+# RoFormerForCausalLM): phone-mode encoder (4 layers) + causal decoder with cross-attention (1 layer) --------------------
+PHONE_SYMBOLS = 108      # len(symbols) in reference text/symbols.py:1-33 (pad + sorted phone set + punctuation)
+NUM_TONES = 11           # reference text/symbols.py:36 (6 zh + 1 ja + 4 en)
+
+
+def roformer_config(n_spk=323, semantic_kmeans_num=4096, hidden_size=256, num_attention_heads=8, intermediate_size=512,
+                    encoder_layers=4, decoder_layers=1, max_position_embeddings=3072, layer_norm_eps=1e-12):
+    """Shapes of `get_model(n_spk, **config['text2semantic'])` in phone mode (reference configs/config.yaml:56-83)."""
+    return dict(n_spk=n_spk, semantic_kmeans_num=semantic_kmeans_num, hidden=hidden_size, heads=num_attention_heads,
+                inter=intermediate_size, enc_layers=encoder_layers, dec_layers=decoder_layers, max_pos=max_position_embeddings,
+                eps=float(layer_norm_eps), text_vocab=PHONE_SYMBOLS + 3, type_vocab=NUM_TONES + 1,
+                text_bos=PHONE_SYMBOLS, text_eos=PHONE_SYMBOLS + 1, text_pad=PHONE_SYMBOLS + 2,
+                sem_vocab=semantic_kmeans_num + 3, sem_bos=semantic_kmeans_num, sem_eos=semantic_kmeans_num + 1,
+                sem_pad=semantic_kmeans_num + 2)
+
+
+def _roformer_attention(d, p, h):
+    for n in ("query", "key", "value"):
+        d[p + f"self.{n}.weight"] = (h, h)
+        d[p + f"self.{n}.bias"] = (h,)
+    d[p + "output.dense.weight"] = (h, h)
+    d[p + "output.dense.bias"] = (h,)
+    d[p + "output.LayerNorm.weight"] = (h,)
+    d[p + "output.LayerNorm.bias"] = (h,)
+
+
+def _roformer_stack(d, p, cfg, vocab, type_vocab, layers, cross):
+    h, it = cfg["hidden"], cfg["inter"]
+    d[p + "embeddings.word_embeddings.weight"] = (vocab, h)
+    d[p + "embeddings.token_type_embeddings.weight"] = (type_vocab, h)
+    d[p + "embeddings.LayerNorm.weight"] = (h,)
+    d[p + "embeddings.LayerNorm.bias"] = (h,)
+    d[p + "encoder.embed_positions.weight"] = (cfg["max_pos"], h // cfg["heads"])
+    for i in range(layers):
+        q = p + f"encoder.layer.{i}."
+        _roformer_attention(d, q + "attention.", h)
+        if cross:
+            _roformer_attention(d, q + "crossattention.", h)
+        d[q + "intermediate.dense.weight"] = (it, h)
+        d[q + "intermediate.dense.bias"] = (it,)
+        d[q + "output.dense.weight"] = (h, it)
+        d[q + "output.dense.bias"] = (h,)
+        d[q + "output.LayerNorm.weight"] = (h,)
+        d[q + "output.LayerNorm.bias"] = (h,)
+
+
+def roformer_param_shapes(cfg):
+    """`Roformer.state_dict()` key -> shape (reference roformer.py:59-125 over HF RoFormerModel / RoFormerForCausalLM).
+    `*.embed_positions.weight` is the fixed sinusoid table, `cls.predictions.decoder.{weight,bias}` are tied to the word
+    embeddings / `cls.predictions.bias`."""
+    d = OrderedDict()
+    h = cfg["hidden"]
+    _roformer_stack(d, "text_encoder.", cfg, cfg["text_vocab"], cfg["type_vocab"], cfg["enc_layers"], False)
+    _roformer_stack(d, "semantic_decoder.roformer.", cfg, cfg["sem_vocab"], 1, cfg["dec_layers"], True)
+    d["semantic_decoder.cls.predictions.bias"] = (cfg["sem_vocab"],)
+    d["semantic_decoder.cls.predictions.transform.dense.weight"] = (h, h)
+    d["semantic_decoder.cls.predictions.transform.dense.bias"] = (h,)
+    d["semantic_decoder.cls.predictions.transform.LayerNorm.weight"] = (h,)
+    d["semantic_decoder.cls.predictions.transform.LayerNorm.bias"] = (h,)
+    d["semantic_decoder.cls.predictions.decoder.weight"] = (cfg["sem_vocab"], h)
+    d["semantic_decoder.cls.predictions.decoder.bias"] = (cfg["sem_vocab"],)
+    if cfg["n_spk"] is not None and cfg["n_spk"] > 1:
+        d["spk_emb.weight"] = (cfg["n_spk"] + 1, h)
+    return d
+
+
+ROFORMER_TIED = {"semantic_decoder.cls.predictions.decoder.weight": "semantic_decoder.roformer.embeddings.word_embeddings.weight",
+                 "semantic_decoder.cls.predictions.decoder.bias": "semantic_decoder.cls.predictions.bias"}
+
+
+def roformer_sinusoid_table(n_pos, dim):
+    """HF RoFormerSinusoidalPositionalEmbedding.create_weight: [sin(pos * w_i) | cos(pos * w_i)], w_i = 10000^(-2i/dim),
+    evaluated in float64 and rounded to fp32 once."""
+    import numpy as np
+    pos = np.arange(n_pos, dtype=np.float64)[:, None]
+    inv = 1.0 / np.power(10000.0, 2.0 * np.arange(dim // 2, dtype=np.float64) / dim)
+    ang = pos * inv[None, :]
+    return np.concatenate([np.sin(ang), np.cos(ang)], axis=1).astype(np.float32)
+
+
+def roformer_init_state(cfg, seed=0, init_weights=None):
+    """Build-owned seeded weights for the LM (no checkpoint ships): per-key integer RNG, tied tensors made identical, the
+    position tables computed.  `init_weights` = the lds.init_weights module when this file is loaded outside the package."""
+    if init_weights is None:
+        from . import init_weights
+    import numpy as np
+    shapes = roformer_param_shapes(cfg)
+    st = init_weights.init_state(shapes, seed)
+    for k in shapes:
+        if k.endswith("embed_positions.weight"):
+            st[k] = roformer_sinusoid_table(*shapes[k])
+        elif "LayerNorm.weight" in k:
+            st[k] = init_weights.uniform(k, shapes[k], seed, 0.8, 1.2)
+        elif "embeddings.weight" in k or k == "spk_emb.weight":
+            st[k] = init_weights.uniform(k, shapes[k], seed, -1.0, 1.0)
+    for dst, src in ROFORMER_TIED.items():
+        st[dst] = st[src]
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in st.items()}

@@ -15,6 +15,10 @@ reference.  Writes small .npz/.json files (default: next to this script, `--out 
   vocoder_rb2.npz     Generator forward with resblock '2' (reference models.py:201-222)
   units_align.npz     units_forced_alignment (reference tools/tools.py:193-223): nearest by scale factor / by size, 'left'
   resume.json         which checkpoint tools/utils.py:load_model restores from a directory of model_<step>.pt files
+  roformer.npz        text2semantic RoFormer (reference text2semantic/roformer/roformer.py over HF transformers; phone mode, the
+                      reference's own flash-attention wrapper off): encoder states, per-step logits and token sequences of
+                      generate() -- greedy, top-k sampling with recorded uniforms, and an early-EOS case
+  manifest_roformer.json  Roformer.state_dict() key -> shape
 
 Weights always come from the build-owned seeded initialiser (lds/init_weights.py) loaded
 into the reference modules with load_state_dict, so they can be regenerated anywhere.
@@ -378,6 +382,83 @@ def main():
                 picked[cname] = {"files": files, "raises": type(e).__name__}
     print("resume", picked)
     json.dump(picked, open(path("resume.json"), "w"), indent=1)
+
+    roformer_fixtures(path)
+
+
+def roformer_fixtures(path):
+    """text2semantic LM.  Pinned to the installed transformers (RoFormerModel / RoFormerForCausalLM / GenerationMixin)."""
+    import transformers
+    import yaml
+    from text2semantic.roformer import roformer as ref_lm
+    assert os.path.realpath(inspect.getfile(ref_lm)).startswith(REF + os.sep)
+    args = yaml.safe_load(open(os.path.join(REF, "configs", "config.yaml")))
+    t2s = args["text2semantic"]
+    t2s["model"]["mode"] = "phone"                 # 'text' mode fetches a tokenizer from the hub (unavailable offline)
+    t2s["model"]["codebook_path"] = "/nonexistent"   # no codebook ships; the constructor's try/except skips it
+    t2s["train"]["use_flash_attn"] = False         # the reference's wrapper targets an older transformers API
+    cfg = arch.roformer_config(n_spk=args["common"]["n_spk"], semantic_kmeans_num=t2s["model"]["semantic_kmeans_num"])
+    m = ref_lm.get_model(args["common"]["n_spk"], **t2s).eval()
+    json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, open(path("manifest_roformer.json"), "w"), indent=0)
+    state = arch.roformer_init_state(cfg, SEED_W, init_weights)
+    m.load_state_dict({k: tt(v) for k, v in state.items()}, strict=True)
+    assert np.array_equal(m.text_encoder.encoder.embed_positions.weight.numpy(), state["text_encoder.encoder.embed_positions.weight"])
+
+    B, L = 2, 23
+    phone = (np.arange(B * L).reshape(B, L) * 7 % 107 + 1).astype(np.int64)
+    tone = (np.arange(B * L).reshape(B, L) * 5 % 12).astype(np.int64)
+    spk = np.stack([np.full(L, 3), np.full(L, 200)]).astype(np.int64)
+    out = {"phone": phone, "tone": tone, "spk_id": spk, "transformers_version": np.frombuffer(transformers.__version__.encode(), dtype=np.uint8)}
+
+    logits = []
+    hook = m.semantic_decoder.cls.register_forward_hook(lambda _m, _i, o: logits.append(o[:, -1].detach().numpy().copy()))
+    enc = []
+    hook2 = m.text_encoder.register_forward_hook(lambda _m, _i, o: enc.append(o[0].detach().numpy().copy()))
+    # use_cache=False: under transformers 5.x generate() hands RoFormerForCausalLM a plain DynamicCache (the model is not flagged
+    # encoder-decoder), and RoFormerSelfAttention then stores the cross-attention keys/values in the SAME cache slot as the
+    # self-attention ones (modeling_roformer.py:160-185) -- an artefact of running the unpinned reference on a newer library, not
+    # the model's semantics.  Without the cache the same reference code evaluates the intended computation (one decoder layer:
+    # the last position sees exactly the causal context).
+    kw = dict(attention_mask=None, use_cache=False, temperature=1.0, top_k=5, top_p=1.0, repetition_penalty=1.0, num_beams=1,
+              no_repeat_ngram_size=0, early_stopping=True, spk_id=tt(spk), end_gate_threshold=None)      # 22_infer_tts.py:83-98
+
+    real_multinomial = torch.multinomial
+    drawn = []
+
+    def inverse_cdf_multinomial(probs, num_samples, **_k):
+        # the sampler's draw made reproducible outside torch: u ~ U[0,1) recorded, token = first index whose running sum exceeds u
+        assert num_samples == 1
+        u = torch.rand(probs.shape[0])
+        drawn.append(u.numpy().copy())
+        c = probs.float().cumsum(-1)
+        return torch.searchsorted(c, u[:, None].contiguous(), right=True).clamp(max=probs.shape[-1] - 1)
+
+    def run(tag, do_sample, max_length, eos_bias=None):
+        if eos_bias is not None:
+            m.semantic_decoder.cls.predictions.bias.data[cfg["sem_eos"]] += eos_bias
+        del logits[:], enc[:], drawn[:]
+        torch.manual_seed(5)
+        torch.multinomial = inverse_cdf_multinomial
+        try:
+            toks = m.generate(tt(phone), tt(tone), max_length=max_length, do_sample=do_sample, **kw).numpy()
+        finally:
+            torch.multinomial = real_multinomial
+            if eos_bias is not None:
+                m.semantic_decoder.cls.predictions.bias.data[cfg["sem_eos"]] -= eos_bias
+        out[tag + "_tokens"] = toks
+        out[tag + "_logits"] = np.stack(logits)
+        if do_sample:
+            out[tag + "_uniforms"] = np.stack(drawn)
+        print("roformer", tag, toks.shape, "logit absmax", float(np.abs(out[tag + "_logits"]).max()), toks[:, :10].tolist())
+        return enc[0]
+
+    out["enc"] = run("greedy", False, 24)
+    run("sample", True, 40)
+    out["eos_bias"] = np.float32(21.0)
+    run("eos", True, 40, eos_bias=21.0)
+    hook.remove()
+    hook2.remove()
+    np.savez_compressed(path("roformer.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -14,8 +14,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
-FILES_NPZ = ["schedule.npz", "unet_fwd.npz", "solver_toy.npz", "sampler.npz", "sampler_shallow.npz", "vocoder.npz", "vocoder_rb2.npz", "units_align.npz"]
-FILES_JSON = ["manifest_unet.json", "manifest_generator.json", "manifest_diffusion_buffers.json", "resume.json"]
+FILES_NPZ = ["schedule.npz", "unet_fwd.npz", "solver_toy.npz", "sampler.npz", "sampler_shallow.npz", "vocoder.npz", "vocoder_rb2.npz", "units_align.npz", "roformer.npz"]
+FILES_JSON = ["manifest_unet.json", "manifest_generator.json", "manifest_diffusion_buffers.json", "resume.json", "manifest_roformer.json"]
 
 
 def regenerate(out_dir):
