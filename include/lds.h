@@ -139,6 +139,36 @@ int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out)
 int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes,
                         int B, int T, void* stream);
 
+/* ---- text2semantic: RoFormer encoder prefill + cached autoregressive decode (reference text2semantic/roformer/roformer.py:59-255
+ *      over HF transformers RoFormerModel / RoFormerForCausalLM + GenerationMixin; called from 22_infer_tts.py:76-98) ------------- */
+typedef struct lds_lm lds_lm;
+typedef struct {
+    int hidden, heads, inter;          /* 256, 8, 512 (reference configs/config.yaml:60-83)                          */
+    int enc_layers, dec_layers;        /* 4, 1                                                                        */
+    int text_vocab, type_vocab;        /* phone symbols + 3, tones + 1                                                */
+    int sem_vocab;                     /* semantic_kmeans_num + 3                                                     */
+    int n_spk_rows;                    /* rows of spk_emb (n_spk + 1), 0 = no speaker embedding                       */
+    int max_pos;                       /* rows of the sinusoid tables                                                 */
+    float eps;                         /* layer_norm_eps                                                              */
+    int sem_bos, sem_eos, sem_pad;
+} lds_lm_cfg;
+/* names = the reference Roformer.state_dict() keys (text_encoder.*, semantic_decoder.*, spk_emb.weight), fp32 host arrays */
+int lds_lm_create(const lds_lm_cfg* cfg, int n_tensors, const char* const* names, const float* const* host_ptrs, const int64_t* numel,
+                  lds_lm** out);
+void lds_lm_destroy(lds_lm* lm);
+int lds_lm_workspace_bytes(const lds_lm* lm, int B, int L, int max_length, size_t* out);
+/* phone, tone, spk_id: dev int64 [B,L] (spk_id may be NULL) -> enc dev [B,L,hidden] = encoder_hidden_states (roformer.py:196-204) */
+int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, float* enc, void* ws, size_t ws_bytes,
+                  int B, int L, void* stream);
+/* Roformer.generate (roformer.py:179-240): greedy (do_sample 0) or RepetitionPenalty -> Temperature -> TopK -> TopP -> one draw per
+ * step.  uniforms dev [max_length-1][B]: the draw is the inverse-CDF rule over the vocabulary order with these numbers (torch's own
+ * multinomial stream cannot be reproduced outside torch).  tokens dev int64 [B][max_length] (BOS first; finished sequences padded);
+ * logits_out optional dev [max_length-1][B][sem_vocab]; *n_tokens_host = length of the returned sequences incl. BOS.  The call
+ * synchronises the stream every 8 steps to poll for EOS. */
+int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int max_length, int do_sample, int top_k, float top_p, float temperature,
+                    float repetition_penalty, const float* uniforms, int64_t* tokens, float* logits_out, int* n_tokens_host, void* ws,
+                    size_t ws_bytes, void* stream);
+
 /* ---- per-launch HIP-event timing for bench.py's roofline leg (off by default) ------------------
  * lds_prof_enable(1) clears and starts recording one event pair per kernel launch on the launch
  * stream; lds_prof_summary synchronises them and writes a JSON list of

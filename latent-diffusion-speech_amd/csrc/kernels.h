@@ -158,6 +158,9 @@ hipError_t launch_resample_nearest(const float* in, float* out, int B, int C, in
 // ---------------------------------------------------------------------------------------------
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
 // ---------------------------------------------------------------------------------------------
+// records the thread-local message returned by lds_last_error() and returns `code` (model.hip)
+int set_error(int code, const char* fmt, ...);
+
 struct ProfScope {
     bool on;
     hipStream_t s;

@@ -1,0 +1,619 @@
+// text2semantic RoFormer on gfx950 (reference text2semantic/roformer/roformer.py:59-255 over HF transformers RoFormerModel /
+// RoFormerForCausalLM + GenerationMixin): phone/tone encoder prefill and the key/value-cached autoregressive decode with greedy or
+// top-k / top-p sampling.  The model is tiny (hidden 256, 4 + 1 layers, 4.3 M parameters) and the caller decodes one to a few
+// utterances, so every step is launch- and latency-bound: the design keeps the whole loop on the stream (no host round trip except
+// an EOS poll every few steps), fuses bias / residual / LayerNorm / GELU into the matrix-vector kernels and reads each weight once
+// per step with coalesced loads (weights stored transposed [K][M]).  Accumulation is one fp32 fmaf chain over k in ascending order
+// per output, independent of the batch size.
+#include "../../include/lds.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace lds {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over the 256 threads of a workgroup (fixed order), result in every thread
+static __device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+static __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---- embeddings: x = LN(word[tok] + type[tt]); encoder: x = LN(x + spk[spk_id] + type[0]) as well (roformer.py:196, the
+//      embeddings module is applied a second time to inputs_embeds).  One workgroup per token, H <= 1024. ----
+__global__ void __launch_bounds__(256) lm_embed_kernel(const float* __restrict__ word, const float* __restrict__ type, const float* __restrict__ spk,
+                                                       const float* __restrict__ g, const float* __restrict__ bta, const int64_t* __restrict__ tok,
+                                                       int tok_stride, const int64_t* __restrict__ tt, const int64_t* __restrict__ spk_id, int twice,
+                                                       float eps, int H, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const long long t = tok[(long long)n * tok_stride];
+    const long long ty = tt ? tt[n] : 0;
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = (c < H) ? word[t * H + c] + type[ty * H + c] : 0.f;
+        s += v[i];
+    }
+    for (int pass = 0; pass < (twice ? 2 : 1); ++pass) {
+        const float mean = block_sum256(s, red) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = (tid + 256 * i < H) ? v[i] - mean : 0.f; q += d * d; }
+        const float rstd = 1.0f / sqrtf(block_sum256(q, red) / (float)H + eps);
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if (c < H) {
+                v[i] = (v[i] - mean) * rstd * g[c] + bta[c];
+                if (pass == 0 && twice) v[i] += (spk && spk_id ? spk[spk_id[n] * H + c] : 0.f) + type[c];
+            }
+            s += (c < H) ? v[i] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (tid + 256 * i < H) out[(long long)n * H + tid + 256 * i] = v[i];
+}
+
+// ---- Y[n][m] = epi(sum_k X[n][k] * Wt[k][m] + b[m]) for a tile of 8 tokens per workgroup, one output column per thread.
+//      EPI 0: none, 1: GELU, 2: LayerNorm(y + R[n][m]) over m (needs M == 256 = the workgroup), 3: LayerNorm(GELU(y)). ----
+template <int EPI>
+__global__ void __launch_bounds__(256) lm_linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                        const float* __restrict__ R, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                        float* __restrict__ Y, int ldy, int N, int K, int M) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [K][8]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, m = blockIdx.x * 256 + tid, n0 = blockIdx.y * 8;
+    for (int i = tid; i < K * 8; i += 256) {
+        const int k = i >> 3, j = i & 7;
+        xs[i] = (n0 + j < N) ? X[(long long)(n0 + j) * ldx + k] : 0.f;
+    }
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+        const float* wp = Wt + m;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float w = wp[(long long)k * M];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + 8 * k), b = *reinterpret_cast<const f32x4*>(xs + 8 * k + 4);
+            acc[0] = fmaf(w, a[0], acc[0]); acc[1] = fmaf(w, a[1], acc[1]); acc[2] = fmaf(w, a[2], acc[2]); acc[3] = fmaf(w, a[3], acc[3]);
+            acc[4] = fmaf(w, b[0], acc[4]); acc[5] = fmaf(w, b[1], acc[5]); acc[6] = fmaf(w, b[2], acc[6]); acc[7] = fmaf(w, b[3], acc[7]);
+        }
+    }
+    const float bm = (m < M && bias) ? bias[m] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float y = acc[j] + bm;
+        const bool ok = m < M && n0 + j < N;
+        if constexpr (EPI == 1 || EPI == 3) y = gelu_erf(y);
+        if constexpr (EPI == 2) { if (ok && R) y += R[(long long)(n0 + j) * M + m]; }
+        if constexpr (EPI >= 2) {      // LayerNorm over the row (M == 256: every thread holds one element of it)
+            const float mean = block_sum256(ok ? y : 0.f, red) / (float)M;
+            const float d = ok ? y - mean : 0.f;
+            const float rstd = 1.0f / sqrtf(block_sum256(d * d, red) / (float)M + eps);
+            y = d * rstd * (m < M ? g[m] : 0.f) + (m < M ? bta[m] : 0.f);
+        }
+        if (ok) Y[(long long)(n0 + j) * ldy + m] = y;
+    }
+}
+
+// ---- rotary position embedding of q and k (modeling_roformer.py:220-245; table row = [sin(16) | cos(16)] for head dim 32) and
+//      the key/value cache append.  qkv [N][3H] (q | k | v); token n = (b, l) with position pos0 + l; k', v go to
+//      kc / vc [B][heads][cap][d] at slot pos0 + l.  One thread per (token, head, pair). ----
+__global__ void __launch_bounds__(256) lm_rope_kernel(float* __restrict__ qkv, const float* __restrict__ table, int B, int L, int pos0, int H, int heads,
+                                                      float* __restrict__ kc, float* __restrict__ vc, int cap) {
+    const int d = H / heads, hp = d / 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * L * heads * hp) return;
+    const int p = (int)(i % hp), hd = (int)((i / hp) % heads);
+    const long long n = i / ((long long)hp * heads);
+    const int l = (int)(n % L), b = (int)(n / L);
+    const float sn = table[(long long)(pos0 + l) * d + p], cs = table[(long long)(pos0 + l) * d + hp + p];
+    float* q = qkv + n * 3 * H + hd * d + 2 * p;
+    float* k = q + H;
+    const float q0 = q[0], q1 = q[1], k0 = k[0], k1 = k[1];
+    q[0] = q0 * cs - q1 * sn; q[1] = q1 * cs + q0 * sn;
+    const float r0 = k0 * cs - k1 * sn, r1 = k1 * cs + k0 * sn;
+    k[0] = r0; k[1] = r1;
+    const long long co = (((long long)b * heads + hd) * cap + pos0 + l) * d + 2 * p;
+    kc[co] = r0; kc[co + 1] = r1;
+    const float* v = k + H;
+    vc[co] = v[0]; vc[co + 1] = v[1];
+}
+
+// cross-attention keys / values of the encoder states into the cache layout: kv [N][2H] (k | v) -> kc / vc [B][heads][cap][d]
+__global__ void __launch_bounds__(256) lm_kv_pack_kernel(const float* __restrict__ kv, int B, int L, int H, int heads, float* __restrict__ kc,
+                                                         float* __restrict__ vc, int cap) {
+    const int d = H / heads;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * L * H) return;
+    const int c = (int)(i % H);
+    const long long n = i / H;
+    const int l = (int)(n % L), b = (int)(n / L), hd = c / d, e = c - hd * d;
+    const long long co = (((long long)b * heads + hd) * cap + l) * d + e;
+    kc[co] = kv[n * 2 * H + c];
+    vc[co] = kv[n * 2 * H + H + c];
+}
+
+// ---- attention of one query per wave: softmax(q K^T / sqrt(d)) V over Lk cached keys (no mask: the decoder's cache holds exactly the
+//      causal context, the encoder is bidirectional).  q [N][ldq] (head slice at hd*d), out [N][H].  Phase 1: one key per lane;
+//      phase 2: one output channel per lane, the two half-waves take alternate keys.  d <= 32. ----
+__global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kc, const float* __restrict__ vc, int cap,
+                                                      int Lq, int Lk, int H, int heads, int total, float* __restrict__ out) {
+    extern __shared__ float sc[];                      // [4 waves][Lk rounded]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;            // (b, l, head)
+    const int d = H / heads, Lkp = (Lk + 63) & ~63;
+    if (item >= total) return;
+    const int hd = item % heads;
+    const long long n = item / heads;                  // token index b * Lq + l
+    const int b = (int)(n / Lq);
+    float* s = sc + wave * Lkp;
+    float qr[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) qr[e] = (e < d) ? q[n * ldq + hd * d + e] : 0.f;
+    const float* kb = kc + ((long long)b * heads + hd) * cap * d;
+    const float* vb = vc + ((long long)b * heads + hd) * cap * d;
+    const float scale = 1.0f / sqrtf((float)d);
+    float mx = -INFINITY;
+    for (int k0 = 0; k0 < Lk; k0 += 64) {
+        const int key = k0 + lane;
+        float dot = -INFINITY;
+        if (key < Lk) {
+            dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e)
+                if (e < d) dot = fmaf(qr[e], kb[(long long)key * d + e], dot);
+            dot *= scale;
+        }
+        s[key < Lkp ? key : 0] = dot;      // key < Lkp always (k0 + lane < Lkp)
+        mx = fmaxf(mx, dot);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k0 = 0; k0 < Lk; k0 += 64) {
+        const int key = k0 + lane;
+        const float p = (key < Lk) ? expf(s[key] - mx) : 0.f;
+        s[key] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's LDS writes are done before its reads below
+    const int e = lane & 31, half = lane >> 5;
+    float acc = 0.f;
+    if (e < d)
+        for (int key = half; key < Lk; key += 2) acc = fmaf(s[key], vb[(long long)key * d + e], acc);
+    acc += __shfl_xor(acc, 32, 64);
+    if (half == 0 && e < d) out[n * H + hd * d + e] = acc / sum;
+}
+
+// ---- next-token choice per sequence (HF GenerationMixin._sample with RepetitionPenalty -> Temperature -> TopK -> TopP, then
+//      softmax + one draw; greedy = argmax).  The draw is the inverse-CDF rule over the vocabulary order with a caller-supplied
+//      uniform (torch.multinomial's own stream cannot be reproduced outside torch).  One workgroup per sequence, V <= 256 * 32. ----
+constexpr int kMaxTopK = 64;
+__global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict__ logits, int V, int do_sample, int top_k, float top_p, float inv_temp,
+                                                        float rep_pen, const float* __restrict__ uniforms, int64_t* __restrict__ tokens, int cap_tokens,
+                                                        int step, int* __restrict__ unfinished, int eos, int pad, int* __restrict__ any_unfinished) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    __shared__ float topv[kMaxTopK];
+    __shared__ int topi[kMaxTopK];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = logits + (long long)b * V;
+    int64_t* seq = tokens + (long long)b * cap_tokens;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = (c < V) ? lg[c] : -INFINITY;
+    }
+    if (rep_pen != 1.0f) {      // RepetitionPenaltyLogitsProcessor: every distinct token of the sequence so far is penalised once (gather / scatter)
+        unsigned done = 0;
+        for (int j = 0; j <= step; ++j) {
+            const int t = (int)seq[j];
+            if ((t & 255) == tid && !((done >> (t >> 8)) & 1u)) {
+                done |= 1u << (t >> 8);
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (i == (t >> 8)) v[i] = (v[i] < 0.f) ? v[i] * rep_pen : v[i] / rep_pen;
+            }
+        }
+    }
+    if (do_sample && inv_temp != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] *= inv_temp;
+    }
+    const int rounds = do_sample ? top_k : 1;
+    for (int r = 0; r < rounds; ++r) {      // r-th largest remaining value, ties to the lowest index
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = tid + 256 * i;
+            if (v[i] > bv || (v[i] == bv && c < bi && v[i] > -INFINITY)) { bv = v[i]; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+        __syncthreads();
+        bv = rv[0]; bi = ri[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+        if (tid == 0) { topv[r] = bv; topi[r] = bi; }
+        if ((bi & 255) == tid) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i == (bi >> 8)) v[i] = -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int next;
+        if (!do_sample) {
+            next = topi[0];
+        } else {
+            // softmax over the survivors (descending order in topv), optional nucleus cut, renormalise, draw in vocabulary order
+            int kept = top_k;
+            float pr[kMaxTopK];
+            float sum = 0.f;
+            for (int j = 0; j < kept; ++j) { pr[j] = expf(topv[j] - topv[0]); sum += pr[j]; }
+            if (top_p < 1.0f) {      // TopPLogitsWarper: drop the tail whose ascending cumulative probability stays <= 1 - top_p
+                float tail = 0.f;
+                int cut = kept;
+                for (int j = kept - 1; j >= 1; --j) {
+                    tail += pr[j] / sum;
+                    if (tail <= 1.0f - top_p) cut = j; else break;
+                }
+                kept = cut;
+                sum = 0.f;
+                for (int j = 0; j < kept; ++j) sum += pr[j];
+            }
+            for (int j = 0; j < kept; ++j) pr[j] = pr[j] / sum;
+            // vocabulary order (insertion sort of <= 64 entries), running sum, first index whose sum exceeds u
+            int ord[kMaxTopK];
+            for (int j = 0; j < kept; ++j) ord[j] = j;
+            for (int j = 1; j < kept; ++j) {
+                const int o = ord[j];
+                int q = j - 1;
+                while (q >= 0 && topi[ord[q]] > topi[o]) { ord[q + 1] = ord[q]; --q; }
+                ord[q + 1] = o;
+            }
+            const float u = uniforms[b];
+            float c = 0.f;
+            next = topi[ord[kept - 1]];
+            for (int j = 0; j < kept; ++j) {
+                c += pr[ord[j]];
+                if (c > u) { next = topi[ord[j]]; break; }
+            }
+        }
+        const int alive = unfinished[b];
+        if (!alive) next = pad;
+        seq[step + 1] = next;
+        if (alive && next == eos) unfinished[b] = 0;
+        if (alive && next != eos) atomicOr(any_unfinished + step, 1);      // flag array indexed by step, zeroed by the host wrapper
+    }
+}
+
+}  // namespace lds
+
+using namespace lds;
+
+// ================================================================================================
+// host side
+// ================================================================================================
+#define lm_fail lds::set_error
+
+#define LM_HIP(expr)                                                                                                    \
+    do {                                                                                                                \
+        hipError_t e_ = (expr);                                                                                         \
+        if (e_ != hipSuccess) return lm_fail(LDS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct LmLinear { float* wt = nullptr; float* b = nullptr; int K = 0, M = 0; };
+struct LmLN { float* g = nullptr; float* b = nullptr; };
+struct LmAttn { LmLinear qkv, q, kv, o; LmLN ln; };      // self: qkv fused; cross: q and kv separately
+struct LmLayer { LmAttn self, cross; LmLinear ff1, ff2; LmLN ln_ff; bool has_cross = false; };
+struct LmStack { float *word = nullptr, *type = nullptr, *table = nullptr; LmLN ln_emb; std::vector<LmLayer> layers; };
+
+struct lds_lm {
+    lds_lm_cfg cfg;
+    std::vector<void*> bufs;
+    LmStack enc, dec;
+    float* spk = nullptr;
+    LmLinear head_t, head_d;
+    LmLN head_ln;
+    ~lds_lm() { for (void* p : bufs) (void)hipFree(p); }
+    float* up(const std::vector<float>& h) {
+        void* d = nullptr;
+        if (hipMalloc(&d, h.size() * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        bufs.push_back(d);
+        return (float*)d;
+    }
+};
+
+namespace {
+struct LmTensors {
+    std::map<std::string, std::pair<const float*, int64_t>> m;
+    std::string missing;
+    const float* get(const std::string& k, int64_t n) {
+        auto it = m.find(k);
+        if (it == m.end() || it->second.second != n) { if (missing.empty()) missing = k; return nullptr; }
+        return it->second.first;
+    }
+};
+// reference layout W [M][K] -> transposed [K][M] (several matrices may be concatenated along M)
+bool lm_linear(lds_lm* lm, LmTensors& T, const std::vector<std::string>& prefixes, int K, int Mper, LmLinear& out) {
+    const int M = Mper * (int)prefixes.size();
+    std::vector<float> wt((size_t)K * M), b(M);
+    for (size_t s = 0; s < prefixes.size(); ++s) {
+        const float* w = T.get(prefixes[s] + "weight", (int64_t)Mper * K);
+        const float* bb = T.get(prefixes[s] + "bias", Mper);
+        if (!w || !bb) return false;
+        for (int m = 0; m < Mper; ++m) {
+            for (int k = 0; k < K; ++k) wt[(size_t)k * M + s * Mper + m] = w[(size_t)m * K + k];
+            b[s * Mper + m] = bb[m];
+        }
+    }
+    out.wt = lm->up(wt); out.b = lm->up(b); out.K = K; out.M = M;
+    return out.wt && out.b;
+}
+bool lm_vec(lds_lm* lm, LmTensors& T, const std::string& k, int64_t n, float*& out) {
+    const float* p = T.get(k, n);
+    if (!p) return false;
+    out = lm->up(std::vector<float>(p, p + n));
+    return out != nullptr;
+}
+bool lm_ln(lds_lm* lm, LmTensors& T, const std::string& p, int H, LmLN& out) { return lm_vec(lm, T, p + "weight", H, out.g) && lm_vec(lm, T, p + "bias", H, out.b); }
+bool lm_attn(lds_lm* lm, LmTensors& T, const std::string& p, int H, bool cross, LmAttn& a) {
+    bool ok = true;
+    if (cross) ok = lm_linear(lm, T, {p + "self.query."}, H, H, a.q) && lm_linear(lm, T, {p + "self.key.", p + "self.value."}, H, H, a.kv);
+    else ok = lm_linear(lm, T, {p + "self.query.", p + "self.key.", p + "self.value."}, H, H, a.qkv);
+    return ok && lm_linear(lm, T, {p + "output.dense."}, H, H, a.o) && lm_ln(lm, T, p + "output.LayerNorm.", H, a.ln);
+}
+bool lm_stack(lds_lm* lm, LmTensors& T, const std::string& p, int vocab, int type_vocab, int n_layers, bool cross, LmStack& s) {
+    const lds_lm_cfg& c = lm->cfg;
+    const int H = c.hidden, d = H / c.heads;
+    bool ok = lm_vec(lm, T, p + "embeddings.word_embeddings.weight", (int64_t)vocab * H, s.word) &&
+              lm_vec(lm, T, p + "embeddings.token_type_embeddings.weight", (int64_t)type_vocab * H, s.type) &&
+              lm_ln(lm, T, p + "embeddings.LayerNorm.", H, s.ln_emb) && lm_vec(lm, T, p + "encoder.embed_positions.weight", (int64_t)c.max_pos * d, s.table);
+    for (int i = 0; i < n_layers && ok; ++i) {
+        LmLayer L;
+        const std::string q = p + "encoder.layer." + std::to_string(i) + ".";
+        L.has_cross = cross;
+        ok = lm_attn(lm, T, q + "attention.", H, false, L.self) && (!cross || lm_attn(lm, T, q + "crossattention.", H, true, L.cross)) &&
+             lm_linear(lm, T, {q + "intermediate.dense."}, H, c.inter, L.ff1) && lm_linear(lm, T, {q + "output.dense."}, c.inter, H, L.ff2) &&
+             lm_ln(lm, T, q + "output.LayerNorm.", H, L.ln_ff);
+        s.layers.push_back(L);
+    }
+    return ok;
+}
+}  // namespace
+
+extern "C" int lds_lm_create(const lds_lm_cfg* cfg, int n, const char* const* names, const float* const* ptrs, const int64_t* numel, lds_lm** out) {
+    if (!cfg || !names || !ptrs || !numel || !out) return lm_fail(LDS_EINVAL, "null argument");
+    if (cfg->hidden != 256 || cfg->heads <= 0 || cfg->hidden % cfg->heads || cfg->hidden / cfg->heads > 32 || (cfg->hidden / cfg->heads) % 2 ||
+        cfg->sem_vocab > 256 * 32 || cfg->inter > 4096)
+        return lm_fail(LDS_EINVAL, "unsupported LM shape (hidden must be 256, head dim even and <= 32, vocabulary <= 8192)");
+    LmTensors T;
+    for (int i = 0; i < n; ++i) T.m[names[i]] = {ptrs[i], numel[i]};
+    lds_lm* lm = new lds_lm();
+    lm->cfg = *cfg;
+    const int H = cfg->hidden;
+    bool ok = lm_stack(lm, T, "text_encoder.", cfg->text_vocab, cfg->type_vocab, cfg->enc_layers, false, lm->enc) &&
+              lm_stack(lm, T, "semantic_decoder.roformer.", cfg->sem_vocab, 1, cfg->dec_layers, true, lm->dec);
+    const std::string c = "semantic_decoder.cls.predictions.";
+    ok = ok && lm_linear(lm, T, {c + "transform.dense."}, H, H, lm->head_t) && lm_ln(lm, T, c + "transform.LayerNorm.", H, lm->head_ln) &&
+         lm_linear(lm, T, {c + "decoder."}, H, cfg->sem_vocab, lm->head_d);
+    if (ok && cfg->n_spk_rows > 0) ok = lm_vec(lm, T, "spk_emb.weight", (int64_t)cfg->n_spk_rows * H, lm->spk);
+    if (!ok) {
+        const std::string miss = T.missing;
+        delete lm;
+        if (!miss.empty()) return lm_fail(LDS_EMISSING, "LM weight tensor %s (absent or wrong size)", miss.c_str());
+        return lm_fail(LDS_ENOMEM, "LM weight upload failed");
+    }
+    *out = lm;
+    return LDS_OK;
+}
+extern "C" void lds_lm_destroy(lds_lm* lm) { delete lm; }
+
+namespace {
+struct LmArena {
+    char* base; size_t cap, used = 0; bool ok = true;
+    LmArena(void* p, size_t n) : base((char*)p), cap(n) {}
+    float* f(size_t n) {
+        const size_t bytes = (n * sizeof(float) + 255) & ~(size_t)255;
+        if (base && used + bytes > cap) ok = false;
+        char* p = base ? base + used : nullptr;
+        used += bytes;
+        return (float*)p;
+    }
+};
+struct LmWs { float *x, *y, *qkv, *ctx, *ff, *kv, *logits, *kc_tmp, *vc_tmp; int* flags; std::vector<float*> kc, vc, ckc, cvc; };
+// N = rows processed at once (B * L for the prefill, B for a decode step)
+void lm_plan(const lds_lm* lm, LmArena& A, int B, int L, int cap, LmWs& w) {
+    const lds_lm_cfg& c = lm->cfg;
+    const size_t N = (size_t)B * (L > 1 ? L : 1), H = c.hidden;
+    w.x = A.f(N * H); w.y = A.f(N * H); w.qkv = A.f(N * 3 * H); w.ctx = A.f(N * H); w.ff = A.f(N * c.inter); w.kv = A.f(N * 2 * H);
+    w.logits = A.f((size_t)B * c.sem_vocab);
+    w.kc_tmp = A.f(N * H); w.vc_tmp = A.f(N * H);
+    w.flags = (int*)A.f((size_t)cap + B + 64);
+    w.kc.clear(); w.vc.clear(); w.ckc.clear(); w.cvc.clear();
+    for (int i = 0; i < c.dec_layers; ++i) {
+        w.kc.push_back(A.f((size_t)B * H * cap)); w.vc.push_back(A.f((size_t)B * H * cap));
+        w.ckc.push_back(A.f((size_t)B * H * L)); w.cvc.push_back(A.f((size_t)B * H * L));
+    }
+}
+template <int EPI>
+hipError_t lm_lin(const LmLinear& W, const float* X, int ldx, const float* R, const LmLN* ln, float eps, float* Y, int ldy, int N, hipStream_t st) {
+    if (EPI >= 2 && W.M != 256) return hipErrorInvalidValue;
+    const dim3 grid((W.M + 255) / 256, (N + 7) / 8);
+    hipLaunchKernelGGL(lm_linear_kernel<EPI>, grid, dim3(256), (size_t)W.K * 8 * sizeof(float), st, X, ldx, W.wt, W.b, R, ln ? ln->g : nullptr, ln ? ln->b : nullptr,
+                       eps, Y, ldy, N, W.K, W.M);
+    return hipGetLastError();
+}
+hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* vc, int cap, int B, int Lq, int Lk, const lds_lm_cfg& c, float* out, hipStream_t st) {
+    const int total = B * Lq * c.heads;
+    const size_t lds = (size_t)4 * ((Lk + 63) & ~63) * sizeof(float);
+    hipLaunchKernelGGL(lm_attn_kernel, dim3((total + 3) / 4), dim3(256), lds, st, q, ldq, kc, vc, cap, Lq, Lk, c.hidden, c.heads, total, out);
+    return hipGetLastError();
+}
+// one BERT-style post-LN layer over N = B * L rows; self-attention over [pos0, pos0 + L) appended to the cache (kc, vc)
+int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& w, float* x, float* y, int B, int L, int pos0, float* kc, float* vc, int cap,
+             const float* ckc, const float* cvc, int Lenc, hipStream_t st) {
+    const lds_lm_cfg& c = lm->cfg;
+    const int H = c.hidden, N = B * L;
+    LM_HIP(lm_lin<0>(Ly.self.qkv, x, H, nullptr, nullptr, c.eps, w.qkv, 3 * H, N, st));
+    {
+        const long long work = (long long)N * c.heads * (H / c.heads / 2);
+        hipLaunchKernelGGL(lm_rope_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, w.qkv, s.table, B, L, pos0, H, c.heads, kc, vc, cap);
+        LM_HIP(hipGetLastError());
+    }
+    LM_HIP(lm_attention(w.qkv, 3 * H, kc, vc, cap, B, L, pos0 + L, c, w.ctx, st));
+    LM_HIP(lm_lin<2>(Ly.self.o, w.ctx, H, x, &Ly.self.ln, c.eps, y, H, N, st));
+    float* cur = y;
+    float* oth = x;
+    if (Ly.has_cross) {
+        LM_HIP(lm_lin<0>(Ly.cross.q, cur, H, nullptr, nullptr, c.eps, w.qkv, H, N, st));
+        LM_HIP(lm_attention(w.qkv, H, ckc, cvc, Lenc, B, L, Lenc, c, w.ctx, st));
+        LM_HIP(lm_lin<2>(Ly.cross.o, w.ctx, H, cur, &Ly.cross.ln, c.eps, oth, H, N, st));
+        float* t = cur; cur = oth; oth = t;
+    }
+    LM_HIP(lm_lin<1>(Ly.ff1, cur, H, nullptr, nullptr, c.eps, w.ff, c.inter, N, st));
+    LM_HIP(lm_lin<2>(Ly.ff2, w.ff, c.inter, cur, &Ly.ln_ff, c.eps, oth, H, N, st));
+    if (oth != x) LM_HIP(hipMemcpyAsync(x, oth, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));      // result always in x
+    return LDS_OK;
+}
+}  // namespace
+
+extern "C" int lds_lm_workspace_bytes(const lds_lm* lm, int B, int L, int max_length, size_t* out) {
+    if (!lm || !out || B <= 0 || L <= 0 || max_length < 2) return lm_fail(LDS_EINVAL, "bad argument");
+    LmArena A(nullptr, 0);
+    LmWs w;
+    lm_plan(lm, A, B, L, max_length, w);
+    *out = A.used;
+    return LDS_OK;
+}
+
+// phone, tone [B,L] int64 (dev), spk_id [B,L] int64 or NULL -> enc [B,L,hidden] (dev)
+extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, float* enc, void* ws, size_t ws_bytes, int B,
+                             int L, void* stream) {
+    if (!lm || !phone || !tone || !enc || !ws || B <= 0 || L <= 0) return lm_fail(LDS_EINVAL, "bad argument");
+    const lds_lm_cfg& c = lm->cfg;
+    if (L > c.max_pos) return lm_fail(LDS_EINVAL, "sequence longer than max_position_embeddings");
+    hipStream_t st = (hipStream_t)stream;
+    LmArena A(ws, ws_bytes);
+    LmWs w;
+    lm_plan(lm, A, B, L, 2, w);
+    if (!A.ok) return lm_fail(LDS_ENOMEM, "LM workspace too small: need %zu bytes", A.used);
+    const int N = B * L, H = c.hidden;
+    hipLaunchKernelGGL(lm_embed_kernel, dim3(N), dim3(256), 0, st, lm->enc.word, lm->enc.type, lm->spk, lm->enc.ln_emb.g, lm->enc.ln_emb.b, phone, 1, tone,
+                       lm->spk ? spk_id : nullptr, 1, c.eps, H, w.x);
+    LM_HIP(hipGetLastError());
+    for (const LmLayer& Ly : lm->enc.layers) {
+        // the encoder's "cache" is just this layer's keys / values for all L positions
+        int r = lm_layer(lm, lm->enc, Ly, w, w.x, w.y, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, st);
+        if (r != LDS_OK) return r;
+    }
+    LM_HIP(hipMemcpyAsync(enc, w.x, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));
+    return LDS_OK;
+}
+
+// enc [B,L,hidden] (dev); uniforms [max_length-1][B] (dev, sampling only); tokens [B][max_length] int64 (dev): BOS then the generated ids,
+// positions past the returned length are unspecified; logits_out optional [max_length-1][B][vocab] (dev).  *n_tokens_host = sequence length incl. BOS.
+extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int max_length, int do_sample, int top_k, float top_p, float temperature,
+                               float repetition_penalty, const float* uniforms, int64_t* tokens, float* logits_out, int* n_tokens_host, void* ws,
+                               size_t ws_bytes, void* stream) {
+    if (!lm || !enc || !tokens || !n_tokens_host || !ws || B <= 0 || L <= 0 || max_length < 2) return lm_fail(LDS_EINVAL, "bad argument");
+    const lds_lm_cfg& c = lm->cfg;
+    if (do_sample && (!uniforms || top_k < 1 || top_k > kMaxTopK || top_k > c.sem_vocab || !(top_p > 0.f) || !(temperature > 0.f)))
+        return lm_fail(LDS_EINVAL, "sampling needs uniforms, 1 <= top_k <= %d, top_p > 0, temperature > 0", kMaxTopK);
+    if (max_length > c.max_pos) return lm_fail(LDS_EINVAL, "max_length exceeds max_position_embeddings");
+    hipStream_t st = (hipStream_t)stream;
+    LmArena A(ws, ws_bytes);
+    LmWs w;
+    lm_plan(lm, A, B, L, max_length, w);
+    if (!A.ok) return lm_fail(LDS_ENOMEM, "LM workspace too small: need %zu bytes", A.used);
+    const int H = c.hidden, V = c.sem_vocab;
+    int* unfinished = w.flags;                 // [B]
+    int* any_unf = w.flags + B;                // [max_length]: 1 when a sequence is still running after step s
+    // cross-attention keys / values of every decoder layer, once
+    for (int i = 0; i < c.dec_layers; ++i) {
+        LM_HIP(lm_lin<0>(lm->dec.layers[i].cross.kv, enc, H, nullptr, nullptr, c.eps, w.kv, 2 * H, B * L, st));
+        hipLaunchKernelGGL(lm_kv_pack_kernel, dim3((unsigned)(((long long)B * L * H + 255) / 256)), dim3(256), 0, st, w.kv, B, L, H, c.heads, w.ckc[i], w.cvc[i], L);
+        LM_HIP(hipGetLastError());
+    }
+    {
+        std::vector<int> init(B + max_length, 0);
+        for (int b = 0; b < B; ++b) init[b] = 1;
+        LM_HIP(hipMemcpyAsync(unfinished, init.data(), sizeof(int) * (B + max_length), hipMemcpyHostToDevice, st));
+        std::vector<int64_t> bos((size_t)B * max_length, (int64_t)c.sem_pad);
+        for (int b = 0; b < B; ++b) bos[(size_t)b * max_length] = c.sem_bos;
+        LM_HIP(hipMemcpyAsync(tokens, bos.data(), sizeof(int64_t) * B * max_length, hipMemcpyHostToDevice, st));
+        LM_HIP(hipStreamSynchronize(st));      // the two host staging vectors go out of scope
+    }
+    const float inv_temp = do_sample ? 1.0f / temperature : 1.0f;
+    int n_tokens = max_length;
+    std::vector<int> host_flags(max_length, 0);
+    int checked = 0;
+    for (int step = 0; step + 1 < max_length; ++step) {
+        // token at position `step` -> logits -> token at position step + 1
+        hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, st, lm->dec.word, lm->dec.type, (const float*)nullptr, lm->dec.ln_emb.g, lm->dec.ln_emb.b,
+                           (const int64_t*)(tokens + step), max_length, (const int64_t*)nullptr, (const int64_t*)nullptr, 0, c.eps, H, w.x);
+        LM_HIP(hipGetLastError());
+        for (int i = 0; i < c.dec_layers; ++i) {
+            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, w.x, w.y, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
+            if (r != LDS_OK) return r;
+        }
+        LM_HIP(lm_lin<3>(lm->head_t, w.x, H, nullptr, &lm->head_ln, c.eps, w.y, H, B, st));
+        float* lg = logits_out ? logits_out + (size_t)step * B * V : w.logits;
+        LM_HIP(lm_lin<0>(lm->head_d, w.y, H, nullptr, nullptr, c.eps, lg, V, B, st));
+        hipLaunchKernelGGL(lm_sample_kernel, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
+                           do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+        LM_HIP(hipGetLastError());
+        // EOS poll every 8 steps: the loop ends after the step in which the last running sequence emitted EOS
+        if ((step & 7) == 7 || step + 2 == max_length) {
+            LM_HIP(hipMemcpyAsync(host_flags.data() + checked, any_unf + checked, sizeof(int) * (step + 1 - checked), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            bool done = false;
+            for (int s = checked; s <= step; ++s)
+                if (!host_flags[s]) { n_tokens = s + 2; done = true; break; }
+            checked = step + 1;
+            if (done) break;
+        }
+    }
+    *n_tokens_host = n_tokens;
+    return LDS_OK;
+}

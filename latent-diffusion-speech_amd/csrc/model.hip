@@ -30,6 +30,13 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int lds::set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 extern "C" const char* lds_last_error(void) { return g_err; }
 extern "C" int lds_version(void) { return 1; }
 

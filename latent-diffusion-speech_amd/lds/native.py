@@ -26,6 +26,12 @@ class VocoderCfg(C.Structure):
                 ("resblock_dilation_sizes", (C.c_int * 4) * 4)]
 
 
+class LMCfg(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("inter", C.c_int), ("enc_layers", C.c_int), ("dec_layers", C.c_int),
+                ("text_vocab", C.c_int), ("type_vocab", C.c_int), ("sem_vocab", C.c_int), ("n_spk_rows", C.c_int), ("max_pos", C.c_int),
+                ("eps", C.c_float), ("sem_bos", C.c_int), ("sem_eos", C.c_int), ("sem_pad", C.c_int)]
+
+
 class ConvTest(C.Structure):
     _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("C1", C.c_int), ("C2", C.c_int), ("Tsrc", C.c_int),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("Co", C.c_int), ("K", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
@@ -43,7 +49,8 @@ EXPORTS = [
     "lds_last_error", "lds_version", "lds_unet_create", "lds_unet_destroy", "lds_unet_workspace_bytes",
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_gather_rows", "lds_resample_frames", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
-    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
+    "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_lm_create", "lds_lm_destroy", "lds_lm_workspace_bytes", "lds_lm_encode",
+    "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
     "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
     "lds_test_conv_transpose"]
 
@@ -58,9 +65,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.lds_last_error.restype = C.c_char_p
         for n in EXPORTS:
-            if n not in ("lds_last_error", "lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy"):
+            if n not in ("lds_last_error", "lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy", "lds_lm_destroy"):
                 getattr(L, n).restype = C.c_int
-        for n in ("lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy"):
+        for n in ("lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy", "lds_lm_destroy"):
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_void_p]
         _lib = L
@@ -294,3 +301,56 @@ class Generator:
         check(lib().lds_vocoder_forward(self.h, _dev(z, torch.float32), _dev(wav), _dev(ws), C.c_size_t(ws.numel()), B, T,
                                         _stream()))
         return wav
+
+
+class LM:
+    """text2semantic RoFormer (lds_lm_*): encoder prefill + cached decode loop."""
+
+    def __init__(self, cfg, state):
+        c = LMCfg()
+        c.hidden, c.heads, c.inter = cfg["hidden"], cfg["heads"], cfg["inter"]
+        c.enc_layers, c.dec_layers = cfg["enc_layers"], cfg["dec_layers"]
+        c.text_vocab, c.type_vocab, c.sem_vocab = cfg["text_vocab"], cfg["type_vocab"], cfg["sem_vocab"]
+        c.n_spk_rows = cfg["n_spk"] + 1 if (cfg["n_spk"] is not None and cfg["n_spk"] > 1) else 0
+        c.max_pos, c.eps = cfg["max_pos"], cfg["eps"]
+        c.sem_bos, c.sem_eos, c.sem_pad = cfg["sem_bos"], cfg["sem_eos"], cfg["sem_pad"]
+        n, names, ptrs, numel, keep = _host_tensor_table(state)
+        self.h = C.c_void_p()
+        check(lib().lds_lm_create(C.byref(c), n, names, ptrs, numel, C.byref(self.h)))
+        self.cfg = cfg
+        self.ws = Workspace()
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.lds_lm_destroy(self.h)
+            self.h = None
+
+    def _ws(self, B, L, max_length, device):
+        nb = C.c_size_t()
+        check(lib().lds_lm_workspace_bytes(self.h, B, L, max_length, C.byref(nb)))
+        return self.ws.get(nb.value, device)
+
+    def encode(self, phone, tone, spk_id=None):
+        import torch
+        B, L = phone.shape
+        ph, tn = phone.contiguous().to(torch.int64), tone.contiguous().to(torch.int64)
+        sp = spk_id.contiguous().to(torch.int64) if spk_id is not None else None
+        ws = self._ws(B, L, 2, phone.device)
+        enc = torch.empty(B, L, self.cfg["hidden"], dtype=torch.float32, device=phone.device)
+        check(lib().lds_lm_encode(self.h, _dev(ph, torch.int64), _dev(tn, torch.int64), _dev(sp, torch.int64) if sp is not None else None, _dev(enc),
+                                  _dev(ws), C.c_size_t(ws.numel()), B, L, _stream()))
+        return enc
+
+    def generate(self, enc, max_length, do_sample, top_k, top_p, temperature, repetition_penalty, uniforms=None, return_logits=False):
+        import torch
+        B, L, _ = enc.shape
+        ws = self._ws(B, L, max_length, enc.device)
+        tokens = torch.empty(B, max_length, dtype=torch.int64, device=enc.device)
+        logits = torch.empty(max_length - 1, B, self.cfg["sem_vocab"], dtype=torch.float32, device=enc.device) if return_logits else None
+        n = C.c_int()
+        check(lib().lds_lm_generate(self.h, _dev(enc.contiguous(), torch.float32), B, L, int(max_length), 1 if do_sample else 0, int(top_k or 0),
+                                    C.c_float(top_p), C.c_float(temperature), C.c_float(repetition_penalty),
+                                    _dev(uniforms.contiguous(), torch.float32) if uniforms is not None else None, _dev(tokens),
+                                    _dev(logits) if logits is not None else None, C.byref(n), _dev(ws), C.c_size_t(ws.numel()), _stream()))
+        toks = tokens[:, : n.value].contiguous()
+        return toks, (logits[: n.value - 1] if logits is not None else None)

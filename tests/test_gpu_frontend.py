@@ -94,3 +94,105 @@ def test_infer_tts_cli_synthetic(tmp_path):
     out2 = tmp_path / "demo.wav"
     infer_tts.main(["--synthetic", "--synthetic_tokens", "16", "-s", "250", "-o", str(out2)])
     assert os.path.getsize(out2) == 44 + 2 * 16 * 512
+
+
+# ---- text2semantic RoFormer ----
+@pytest.fixture(scope="module")
+def lm_gpu():
+    import yaml
+    from text2semantic.utils import get_language_model
+    args = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "config_lm_like_reference.yaml")))
+    m = get_language_model(**args).to("cuda").eval()
+    return m
+
+
+def test_roformer_state_dict_and_encoder(golden, lm_gpu):
+    import json
+    g = golden("roformer.npz")
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest_roformer.json")))
+    sd = lm_gpu.state_dict()
+    assert set(sd) == set(man) and all(list(sd[k].shape) == man[k] for k in man)
+    assert sd["semantic_decoder.cls.predictions.decoder.weight"].data_ptr() == sd["semantic_decoder.roformer.embeddings.word_embeddings.weight"].data_ptr()
+    enc = lm_gpu.encode(torch.from_numpy(g["phone"]).cuda(), torch.from_numpy(g["tone"]).cuda(), torch.from_numpy(g["spk_id"]).cuda()).cpu().numpy()
+    assert relmax(enc, g["enc"]) < 2e-5, relmax(enc, g["enc"])
+
+
+@pytest.mark.parametrize("tag,do_sample,max_length", [("greedy", False, 24), ("sample", True, 40), ("eos", True, 40)])
+def test_roformer_generate_vs_reference(golden, lm_gpu, monkeypatch, tag, do_sample, max_length):
+    """Roformer.generate with the call 22_infer_tts.py:83-98 makes (top_k 5, top_p 1, temperature 1, no repetition penalty) against
+    the reference's own token sequences and per-step logits; the sampler's uniforms are the ones recorded from the reference run"""
+    g = golden("roformer.npz")
+    m = lm_gpu
+    bias = m.semantic_decoder.cls.predictions.bias
+    if tag == "eos":
+        with torch.no_grad():
+            bias[m.semantic_eos_token_id] += float(g["eos_bias"])
+        m._native = None
+    try:
+        if do_sample:
+            u = g[tag + "_uniforms"]
+            full = np.zeros((max_length - 1, u.shape[1]), dtype=np.float32)
+            full[: u.shape[0]] = u
+            monkeypatch.setattr(torch, "rand", lambda *a, **k: dev(full))
+        toks, logits = m.generate(torch.from_numpy(g["phone"]).cuda(), torch.from_numpy(g["tone"]).cuda(), attention_mask=None, use_cache=None,
+                                  max_length=max_length, do_sample=do_sample, temperature=1.0, top_k=5, top_p=1.0, repetition_penalty=1.0, num_beams=1,
+                                  no_repeat_ngram_size=0, early_stopping=True, spk_id=torch.from_numpy(g["spk_id"]).cuda(), end_gate_threshold=None,
+                                  return_logits=True)
+    finally:
+        if tag == "eos":
+            with torch.no_grad():
+                bias[m.semantic_eos_token_id] -= float(g["eos_bias"])
+            m._native = None
+    want = g[tag + "_tokens"]
+    assert toks.shape == want.shape, (toks.shape, want.shape)
+    assert np.array_equal(toks.cpu().numpy(), want)
+    assert relmax(logits.cpu().numpy(), g[tag + "_logits"]) < 2e-5
+
+
+def test_roformer_sampling_controls_vs_oracle(lm_gpu):
+    """top_p < 1, temperature != 1 and a repetition penalty (the defaults of Roformer.generate's signature) against the numpy
+    restatement of the HF logits processors, B = 3, 1-token encoder edge case included via L = 1"""
+    from lds import arch
+    from oracle import roformer as R
+    m = lm_gpu
+    cfg = m.cfg
+    w = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    B, L, ML = 3, 1, 20
+    phone = torch.tensor([[5], [17], [60]], device="cuda")
+    tone = torch.tensor([[1], [0], [7]], device="cuda")
+    spk = torch.tensor([[2], [9], [300]], device="cuda")
+    enc = m.encode(phone, tone, spk)
+    assert relmax(enc.cpu().numpy(), R.encoder_forward(w, cfg, phone.cpu().numpy(), tone.cpu().numpy(), spk.cpu().numpy())) < 2e-5
+    rng = np.random.default_rng(3)
+    u = rng.random((ML - 1, B)).astype(np.float32)
+    toks, _ = m.native().generate(enc, ML, True, 8, 0.7, 1.3, 1.2, dev(u), False)
+    # oracle with the same processors
+    kv = R.cross_kv(w, cfg, enc.cpu().numpy())
+    caches = [dict() for _ in range(cfg["dec_layers"])]
+    seq = np.full((B, 1), cfg["sem_bos"], dtype=np.int64)
+    for step in range(ML - 1):
+        lg = R.decoder_step(w, cfg, seq[:, -1], step, caches, kv)
+        nxt = []
+        for b in range(B):
+            s = lg[b].copy()
+            for t in set(seq[b].tolist()):
+                s[t] = s[t] * 1.2 if s[t] < 0 else s[t] / 1.2
+            s = (s / np.float32(1.3)).astype(np.float32)
+            order = np.argsort(-s, kind="stable")[:8]
+            p = np.exp(s[order] - s[order][0]).astype(np.float32)
+            p = p / p.sum()
+            keep = 8
+            tail = 0.0
+            for j in range(7, 0, -1):
+                tail += p[j]
+                if tail <= 1.0 - 0.7:
+                    keep = j
+                else:
+                    break
+            ids, pp = order[:keep], p[:keep] / p[:keep].sum()
+            o = np.argsort(ids)
+            c = np.cumsum(pp[o].astype(np.float32), dtype=np.float32)
+            j = min(int(np.searchsorted(c, u[step, b], side="right")), keep - 1)
+            nxt.append(int(ids[o][j]))
+        seq = np.concatenate([seq, np.array(nxt)[:, None]], axis=1)
+    assert np.array_equal(toks.cpu().numpy(), seq[:, : toks.shape[1]])
