@@ -305,6 +305,35 @@ def extra_legs(args, dev, model, make_inputs):
         "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
         "launches_per_step": int(sum(r["count"] for r in prof)),
     }
+    # ---- configs[5], one GPU's share (8 of 64 utterances): phones -> RoFormer generate (512 tokens) -> units -> mel -> wav ----
+    sys.path.insert(0, ROOT)
+    import infer_tts
+    from lds import native
+    lm = infer_tts.synthetic_lm(dev)
+    voc = Hifi_VAEGAN(None, device=dev, h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
+    Bq, Lp = 8, 64
+    phones = torch.from_numpy((np.arange(Bq * Lp).reshape(Bq, Lp) * 7 % 107 + 1).astype(np.int64)).to(dev)
+    tones = torch.from_numpy((np.arange(Bq * Lp).reshape(Bq, Lp) * 5 % 12).astype(np.int64)).to(dev)
+    codebook = torch.from_numpy(init_weights.uniform("synthetic.codebook", (4096, 1280), 5, -1.7, 1.7)).to(dev)
+    keep = {}
+
+    def lm_only():
+        keep["tok"] = infer_tts.text2semantic(lm, phones, tones, 1, T + 1)      # random weights never emit EOS: exactly T tokens
+
+    def full():
+        lm_only()
+        units = native.gather_rows(codebook, keep["tok"].clamp(max=4095))
+        mel = model(units, None, spk_id=spk[:Bq], infer=True, infer_speedup=1000 // args.nfe, method=args.method)
+        keep["wav"] = voc(mel)
+    dt_lm = timeit(lm_only, 2)
+    dt = timeit(full, 2)
+    assert tuple(keep["tok"].shape) == (Bq, T) and bool(torch.isfinite(keep["wav"]).all())
+    extra["configs5_full_tts_per_gpu"] = {
+        "workload": f"configs[5] per-GPU share: {Bq} utterances, {Lp} phones -> RoFormer top-k sampling of {T} semantic tokens -> {args.nfe}-step "
+                    f"{args.method} -> HiFi-VAEGAN ({T * 512} samples/utt)",
+        "ms_per_step": 1e3 * dt, "x_realtime": Bq * T * FRAME_SEC / dt, "rtf": dt / (Bq * T * FRAME_SEC),
+        "lm_ms": 1e3 * dt_lm, "lm_tokens_per_sec": Bq * T / dt_lm, "lm_us_per_decode_step": 1e6 * dt_lm / T,
+    }
     return extra
 
 

@@ -1,7 +1,7 @@
-"""Harness counterpart of the reference's 22_infer_tts.py from the point where semantic tokens exist
-(22_infer_tts.py:42-52,100-114): tokens -> unit embeddings (k-means codebook row gather in liblds) [-> forced alignment]
--> DiffusionSVC.infer (Unit2Mel sampler + HiFi-VAEGAN vocoder) -> 44.1 kHz wav.
-The text front end and the RoFormer LM that produce the tokens are outside this build's scope.
+"""Harness counterpart of the reference's 22_infer_tts.py (22_infer_tts.py:27-114) from the phone / tone ids on:
+[phones, tones -> text2semantic RoFormer generate ->] semantic tokens -> unit embeddings (k-means codebook row gather in liblds)
+[-> forced alignment] -> DiffusionSVC.infer (Unit2Mel sampler + HiFi-VAEGAN vocoder) -> 44.1 kHz wav.
+The grapheme-to-phoneme front end (text/cleaner.py: pypinyin / jieba / g2p tables) is outside this build's scope.
 
     python infer_tts.py -dm exp/diffusion/model_300000.pt -cb pretrain/semantic_codebook.pt -t tokens.npy -o out.wav
     python infer_tts.py --synthetic -o /tmp/demo.npy        # seeded random weights, synthetic tokens (no checkpoints exist)
@@ -24,6 +24,9 @@ def parse_args(argv=None):
     ap.add_argument("-dm", "--diffusion_model")
     ap.add_argument("-cb", "--codebook", help="semantic_codebook.pt: the reference's KMeans dict (cluster/__init__.py:5-11) or a plain [n_codes, dim] tensor")
     ap.add_argument("-t", "--tokens", help=".npy int array [T] of semantic token ids")
+    ap.add_argument("-lm", "--language_model", help="exp/lm/model_<step>.pt ({'model': Roformer.state_dict()}) with config.yaml next to it")
+    ap.add_argument("-p", "--phones", help=".npy int array [2, L]: phone ids and tone ids (text_to_sequence output); tokens come from the LM")
+    ap.add_argument("--max_length", type=int, default=1024)
     ap.add_argument("-o", "--output", default="output.npy")
     ap.add_argument("-id", "--spk_id", type=int, default=1)
     ap.add_argument("-s", "--speedup", type=int, default=10)
@@ -61,6 +64,36 @@ def load_codebook(path, dev):
         return torch.load(path, map_location=dev).float().contiguous()     # a bare centre matrix
 
 
+def synthetic_lm(dev):
+    """seeded random-init text2semantic model in the reference's phone-mode configuration"""
+    from lds import arch
+    from text2semantic.roformer.roformer import Roformer
+    c = arch.roformer_config()
+    hf = dict(hidden_size=c["hidden"], num_attention_heads=c["heads"], intermediate_size=c["inter"], hidden_act="gelu",
+              max_position_embeddings=c["max_pos"], layer_norm_eps=c["eps"])
+    return Roformer(dict(hf, num_hidden_layers=c["enc_layers"]), dict(hf, num_hidden_layers=c["dec_layers"]), mode="phone",
+                    semantic_kmeans_num=c["semantic_kmeans_num"], codebook_path="", n_spk=c["n_spk"]).to(dev).eval()
+
+
+def load_lm(path, dev):
+    import yaml
+    from text2semantic.utils import get_language_model
+    args = yaml.safe_load(open(os.path.join(os.path.split(path)[0], "config.yaml")))
+    lm = get_language_model(**args).to(dev)
+    lm.load_state_dict(torch.load(path, map_location=torch.device(dev))["model"])
+    return lm.eval()
+
+
+def text2semantic(lm, phones, tones, spk_id=1, max_length=1024):
+    """22_infer_tts.py:76-104: sample the semantic tokens (top-k 5, temperature 1) and strip BOS / EOS.  phones, tones [B,L] int64."""
+    spk = torch.ones_like(phones) * spk_id
+    tok = lm.generate(phones, tones, attention_mask=None, use_cache=None, max_length=max_length, do_sample=True, temperature=1.0, top_k=5, top_p=1.0,
+                      repetition_penalty=1.0, num_beams=1, no_repeat_ngram_size=0, early_stopping=True, spk_id=spk, end_gate_threshold=None)
+    if tok.shape[0] == 1 and int(tok[0, -1]) == lm.semantic_eos_token_id:      # the reference's check is written for one utterance
+        return tok[:, 1:-1]
+    return tok[:, 1:]
+
+
 def synthesize(svc, codebook, tokens, spk_id=1, speedup=10, method="dpm-solver", scale_factor=None):
     """tokens [T] (or [B,T]) int64 on the device -> (units [B,T',C], mel [B,T',M], wav [B,1,T'*hop])"""
     from lds import native
@@ -77,14 +110,25 @@ def synthesize(svc, codebook, tokens, spk_id=1, speedup=10, method="dpm-solver",
 def main(argv=None):
     a = parse_args(argv)
     dev = "cuda"
+    lm = None
     if a.synthetic:
         svc, codebook, tokens = synthetic_pipeline(dev, a.synthetic_tokens)
+        if a.phones:
+            lm = synthetic_lm(dev)
     else:
         from tools.infer_tools import DiffusionSVC
         svc = DiffusionSVC(device=dev)
         svc.load_model(a.diffusion_model)
         codebook = load_codebook(a.codebook, dev)
-        tokens = torch.from_numpy(np.load(a.tokens).astype(np.int64)).to(dev)
+        tokens = torch.from_numpy(np.load(a.tokens).astype(np.int64)).to(dev) if a.tokens else None
+        if a.language_model:
+            lm = load_lm(a.language_model, dev)
+    if a.phones:
+        if lm is None:
+            raise SystemExit("--phones needs --language_model (or --synthetic)")
+        pt = torch.from_numpy(np.load(a.phones).astype(np.int64)).to(dev)
+        tokens = text2semantic(lm, pt[0:1], pt[1:2], a.spk_id, a.max_length)
+        tokens = tokens.clamp(max=codebook.shape[0] - 1)      # pad ids of finished rows (batch > 1) have no codebook row
     _, _, wav = synthesize(svc, codebook, tokens, a.spk_id, a.speedup, a.method, a.scale_factor)
     wav = wav[0, 0].cpu().numpy()
     if a.output.endswith(".wav"):

@@ -31,7 +31,37 @@ static __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// sum over the 256 threads of a workgroup (fixed order), result in every thread
+// sum over the NT threads of a workgroup (fixed order), result in every thread; red has NT / 64 <= 16 slots
+template <int NT>
+static __device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+// eight sums at once (the rows of a token tile): one barrier pair for all of them
+template <int NT>
+static __device__ __forceinline__ void block_sum8(float (&v)[8], float* red8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = wave_sum(v[j]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red8[(threadIdx.x >> 6) * 8 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) t += red8[i * 8 + j];
+        v[j] = t;
+    }
+}
 static __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
@@ -46,11 +76,13 @@ static __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1
 __global__ void __launch_bounds__(256) lm_embed_kernel(const float* __restrict__ word, const float* __restrict__ type, const float* __restrict__ spk,
                                                        const float* __restrict__ g, const float* __restrict__ bta, const int64_t* __restrict__ tok,
                                                        int tok_stride, const int64_t* __restrict__ tt, const int64_t* __restrict__ spk_id, int twice,
-                                                       float eps, int H, float* __restrict__ out) {
+                                                       float eps, int H, int vocab, int type_vocab, int spk_rows, float* __restrict__ out) {
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const long long t = tok[(long long)n * tok_stride];
-    const long long ty = tt ? tt[n] : 0;
+    long long t = tok[(long long)n * tok_stride];
+    long long ty = tt ? tt[n] : 0;
+    t = (t < 0) ? 0 : (t >= vocab ? vocab - 1 : t);                 // ids are validated on the host; this only keeps a corrupted id from faulting
+    ty = (ty < 0) ? 0 : (ty >= type_vocab ? type_vocab - 1 : ty);
     float v[4];
     float s = 0.f;
 #pragma unroll
@@ -71,7 +103,11 @@ __global__ void __launch_bounds__(256) lm_embed_kernel(const float* __restrict__
             const int c = tid + 256 * i;
             if (c < H) {
                 v[i] = (v[i] - mean) * rstd * g[c] + bta[c];
-                if (pass == 0 && twice) v[i] += (spk && spk_id ? spk[spk_id[n] * H + c] : 0.f) + type[c];
+                if (pass == 0 && twice) {
+                    long long sp = (spk && spk_id) ? spk_id[n] : 0;
+                    sp = (sp < 0) ? 0 : (sp >= spk_rows ? spk_rows - 1 : sp);
+                    v[i] += (spk && spk_id ? spk[sp * H + c] : 0.f) + type[c];
+                }
             }
             s += (c < H) ? v[i] : 0.f;
         }
@@ -81,46 +117,86 @@ __global__ void __launch_bounds__(256) lm_embed_kernel(const float* __restrict__
         if (tid + 256 * i < H) out[(long long)n * H + tid + 256 * i] = v[i];
 }
 
-// ---- Y[n][m] = epi(sum_k X[n][k] * Wt[k][m] + b[m]) for a tile of 8 tokens per workgroup, one output column per thread.
-//      EPI 0: none, 1: GELU, 2: LayerNorm(y + R[n][m]) over m (needs M == 256 = the workgroup), 3: LayerNorm(GELU(y)). ----
-template <int EPI>
-__global__ void __launch_bounds__(256) lm_linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                        const float* __restrict__ R, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                                        float* __restrict__ Y, int ldy, int N, int K, int M) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];      // [K][8]
-    __shared__ float red[4];
-    const int tid = threadIdx.x, m = blockIdx.x * 256 + tid, n0 = blockIdx.y * 8;
-    for (int i = tid; i < K * 8; i += 256) {
+// ---- Y[n][m] = epi(sum_k X[n][k] * Wt[k][m] + b[m]) for a tile of 8 tokens per workgroup.  A decode step has 1-8 rows, so the
+//      kernel is a latency problem, not a FLOP problem: a workgroup is COLS output columns x KS K-slices (each thread walks K/KS
+//      weights with 16 coalesced loads in flight), the partial sums meet through LDS in a fixed order (slice 0 adds slices 1, 2, ...).
+//      EPI 0: none, 1: GELU, 2: LayerNorm(y + R[n][m]) over m, 3: LayerNorm(GELU(y)); EPI >= 2 needs COLS == M == 256. ----
+template <int EPI, int COLS, int KS>
+__global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                             const float* __restrict__ R, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                             float* __restrict__ Y, int ldy, int N, int K, int M) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // xs [K][8] then part [KS-1][COLS][8]
+    __shared__ float red8[16 * 8];
+    float* xs = sm;
+    float* part = sm + (size_t)K * 8;
+    const int tid = threadIdx.x, col = tid % COLS, ks = tid / COLS;
+    const int m = blockIdx.x * COLS + col, n0 = blockIdx.y * 8;
+    for (int i = tid; i < K * 8; i += COLS * KS) {
         const int k = i >> 3, j = i & 7;
         xs[i] = (n0 + j < N) ? X[(long long)(n0 + j) * ldx + k] : 0.f;
     }
     __syncthreads();
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int kq = K / KS, k0 = ks * kq;                            // K % (16 * KS) == 0 (checked by the launcher)
     if (m < M) {
-        const float* wp = Wt + m;
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-            const float w = wp[(long long)k * M];
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + 8 * k), b = *reinterpret_cast<const f32x4*>(xs + 8 * k + 4);
-            acc[0] = fmaf(w, a[0], acc[0]); acc[1] = fmaf(w, a[1], acc[1]); acc[2] = fmaf(w, a[2], acc[2]); acc[3] = fmaf(w, a[3], acc[3]);
-            acc[4] = fmaf(w, b[0], acc[4]); acc[5] = fmaf(w, b[1], acc[5]); acc[6] = fmaf(w, b[2], acc[6]); acc[7] = fmaf(w, b[3], acc[7]);
+        const float* wp = Wt + (long long)k0 * M + m;
+        for (int kk = 0; kk < kq; kk += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wp[(long long)(kk + u) * M];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xs + 8 * (k0 + kk + u)), b = *reinterpret_cast<const f32x4*>(xs + 8 * (k0 + kk + u) + 4);
+                acc[0] = fmaf(w[u], a[0], acc[0]); acc[1] = fmaf(w[u], a[1], acc[1]); acc[2] = fmaf(w[u], a[2], acc[2]); acc[3] = fmaf(w[u], a[3], acc[3]);
+                acc[4] = fmaf(w[u], b[0], acc[4]); acc[5] = fmaf(w[u], b[1], acc[5]); acc[6] = fmaf(w[u], b[2], acc[6]); acc[7] = fmaf(w[u], b[3], acc[7]);
+            }
         }
     }
+    if (ks > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[((ks - 1) * COLS + col) * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    if (ks > 0) {
+        if constexpr (EPI >= 2) {      // the LayerNorm reductions below are workgroup-wide: the other slices take part with zeros
+            float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            block_sum8<COLS * KS>(z, red8);      // (returns the totals in z)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = 0.f;
+            block_sum8<COLS * KS>(z, red8);
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += part[(q * COLS + col) * 8 + j];
     const float bm = (m < M && bias) ? bias[m] : 0.f;
+    float y[8];
+    bool ok[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float y = acc[j] + bm;
-        const bool ok = m < M && n0 + j < N;
-        if constexpr (EPI == 1 || EPI == 3) y = gelu_erf(y);
-        if constexpr (EPI == 2) { if (ok && R) y += R[(long long)(n0 + j) * M + m]; }
-        if constexpr (EPI >= 2) {      // LayerNorm over the row (M == 256: every thread holds one element of it)
-            const float mean = block_sum256(ok ? y : 0.f, red) / (float)M;
-            const float d = ok ? y - mean : 0.f;
-            const float rstd = 1.0f / sqrtf(block_sum256(d * d, red) / (float)M + eps);
-            y = d * rstd * (m < M ? g[m] : 0.f) + (m < M ? bta[m] : 0.f);
-        }
-        if (ok) Y[(long long)(n0 + j) * ldy + m] = y;
+        y[j] = acc[j] + bm;
+        ok[j] = m < M && n0 + j < N;
+        if constexpr (EPI == 1 || EPI == 3) y[j] = gelu_erf(y[j]);
+        if constexpr (EPI == 2) { if (ok[j] && R) y[j] += R[(long long)(n0 + j) * M + m]; }
     }
+    if constexpr (EPI >= 2) {      // LayerNorm over each row (COLS == M: slice 0 holds one element of every row per thread); 8 rows at once
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = ok[j] ? y[j] : 0.f;
+        block_sum8<COLS * KS>(t, red8);
+        float dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dv[j] = ok[j] ? y[j] - t[j] / (float)M : 0.f; t[j] = dv[j] * dv[j]; }
+        block_sum8<COLS * KS>(t, red8);
+        const float gm = (m < M) ? g[m] : 0.f, bt = (m < M) ? bta[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = dv[j] * (1.0f / sqrtf(t[j] / (float)M + eps)) * gm + bt;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (ok[j]) Y[(long long)(n0 + j) * ldy + m] = y[j];
 }
 
 // ---- rotary position embedding of q and k (modeling_roformer.py:220-245; table row = [sin(16) | cos(16)] for head dim 32) and
@@ -161,20 +237,20 @@ __global__ void __launch_bounds__(256) lm_kv_pack_kernel(const float* __restrict
     vc[co] = kv[n * 2 * H + H + c];
 }
 
-// ---- attention of one query per wave: softmax(q K^T / sqrt(d)) V over Lk cached keys (no mask: the decoder's cache holds exactly the
-//      causal context, the encoder is bidirectional).  q [N][ldq] (head slice at hd*d), out [N][H].  Phase 1: one key per lane;
-//      phase 2: one output channel per lane, the two half-waves take alternate keys.  d <= 32. ----
+// ---- attention of one query per workgroup: softmax(q K^T / sqrt(d)) V over Lk cached keys (no mask: the decoder's cache holds exactly
+//      the causal context, the encoder is bidirectional).  q [N][ldq] (head slice at hd*d), out [N][H].  The four waves take alternate
+//      64-key blocks; inside a wave, phase 1 has one key per lane (scores), phase 2 one output channel per lane with the two half-waves on
+//      alternate keys; the waves' (max, sum, partial output) meet through LDS in a fixed order.  d <= 32. ----
 __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kc, const float* __restrict__ vc, int cap,
-                                                      int Lq, int Lk, int H, int heads, int total, float* __restrict__ out) {
-    extern __shared__ float sc[];                      // [4 waves][Lk rounded]
+                                                      int Lq, int Lk, int H, int heads, float* __restrict__ out) {
+    extern __shared__ float sc[];                      // [Lk rounded to 64] scores, then 4 x (max, sum, acc[32])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wave;            // (b, l, head)
+    const int item = blockIdx.x;                       // (b, l, head)
     const int d = H / heads, Lkp = (Lk + 63) & ~63;
-    if (item >= total) return;
     const int hd = item % heads;
     const long long n = item / heads;                  // token index b * Lq + l
     const int b = (int)(n / Lq);
-    float* s = sc + wave * Lkp;
+    float* mrg = sc + Lkp;
     float qr[32];
 #pragma unroll
     for (int e = 0; e < 32; ++e) qr[e] = (e < d) ? q[n * ldq + hd * d + e] : 0.f;
@@ -182,7 +258,7 @@ __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ 
     const float* vb = vc + ((long long)b * heads + hd) * cap * d;
     const float scale = 1.0f / sqrtf((float)d);
     float mx = -INFINITY;
-    for (int k0 = 0; k0 < Lk; k0 += 64) {
+    for (int k0 = wave * 64; k0 < Lk; k0 += 256) {
         const int key = k0 + lane;
         float dot = -INFINITY;
         if (key < Lk) {
@@ -192,25 +268,43 @@ __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ 
                 if (e < d) dot = fmaf(qr[e], kb[(long long)key * d + e], dot);
             dot *= scale;
         }
-        s[key < Lkp ? key : 0] = dot;      // key < Lkp always (k0 + lane < Lkp)
+        sc[key] = dot;
         mx = fmaxf(mx, dot);
     }
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int k0 = 0; k0 < Lk; k0 += 64) {
-        const int key = k0 + lane;
-        const float p = (key < Lk) ? expf(s[key] - mx) : 0.f;
-        s[key] = p;
-        sum += p;
+    if (mx > -INFINITY) {
+        for (int k0 = wave * 64; k0 < Lk; k0 += 256) {
+            const int key = k0 + lane;
+            const float p = (key < Lk) ? expf(sc[key] - mx) : 0.f;
+            sc[key] = p;
+            sum += p;
+        }
     }
     sum = wave_sum(sum);
     __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's LDS writes are done before its reads below
     const int e = lane & 31, half = lane >> 5;
     float acc = 0.f;
-    if (e < d)
-        for (int key = half; key < Lk; key += 2) acc = fmaf(s[key], vb[(long long)key * d + e], acc);
+    if (e < d && mx > -INFINITY)
+        for (int k0 = wave * 64; k0 < Lk; k0 += 256) {
+            const int kend = (k0 + 64 < Lk) ? k0 + 64 : Lk;
+            for (int key = k0 + half; key < kend; key += 2) acc = fmaf(sc[key], vb[(long long)key * d + e], acc);
+        }
     acc += __shfl_xor(acc, 32, 64);
-    if (half == 0 && e < d) out[n * H + hd * d + e] = acc / sum;
+    if (lane == 0) { mrg[wave * 34] = mx; mrg[wave * 34 + 1] = sum; }
+    if (half == 0) mrg[wave * 34 + 2 + e] = acc;
+    __syncthreads();
+    if (wave == 0 && half == 0 && e < d) {
+        float m = fmaxf(fmaxf(mrg[0], mrg[34]), fmaxf(mrg[68], mrg[102]));
+        float tot = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = (mrg[w * 34] > -INFINITY) ? expf(mrg[w * 34] - m) : 0.f;
+            tot += mrg[w * 34 + 1] * f;
+            o += mrg[w * 34 + 2 + e] * f;
+        }
+        out[n * H + hd * d + e] = o / tot;
+    }
 }
 
 // ---- next-token choice per sequence (HF GenerationMixin._sample with RepetitionPenalty -> Temperature -> TopK -> TopP, then
@@ -222,8 +316,8 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
                                                         int step, int* __restrict__ unfinished, int eos, int pad, int* __restrict__ any_unfinished) {
     __shared__ float rv[4];
     __shared__ int ri[4];
-    __shared__ float topv[kMaxTopK];
-    __shared__ int topi[kMaxTopK];
+    __shared__ float topv[kMaxTopK], pr[kMaxTopK];
+    __shared__ int topi[kMaxTopK], ord[kMaxTopK];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* lg = logits + (long long)b * V;
     int64_t* seq = tokens + (long long)b * cap_tokens;
@@ -286,7 +380,6 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
         } else {
             // softmax over the survivors (descending order in topv), optional nucleus cut, renormalise, draw in vocabulary order
             int kept = top_k;
-            float pr[kMaxTopK];
             float sum = 0.f;
             for (int j = 0; j < kept; ++j) { pr[j] = expf(topv[j] - topv[0]); sum += pr[j]; }
             if (top_p < 1.0f) {      // TopPLogitsWarper: drop the tail whose ascending cumulative probability stays <= 1 - top_p
@@ -302,7 +395,6 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
             }
             for (int j = 0; j < kept; ++j) pr[j] = pr[j] / sum;
             // vocabulary order (insertion sort of <= 64 entries), running sum, first index whose sum exceeds u
-            int ord[kMaxTopK];
             for (int j = 0; j < kept; ++j) ord[j] = j;
             for (int j = 1; j < kept; ++j) {
                 const int o = ord[j];
@@ -318,6 +410,7 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
                 if (c > u) { next = topi[ord[j]]; break; }
             }
         }
+        if (next < 0 || next >= V) next = pad;                          // all-NaN logits: nothing compares greater than -inf
         const int alive = unfinished[b];
         if (!alive) next = pad;
         seq[step + 1] = next;
@@ -478,20 +571,23 @@ void lm_plan(const lds_lm* lm, LmArena& A, int B, int L, int cap, LmWs& w) {
 }
 template <int EPI>
 hipError_t lm_lin(const LmLinear& W, const float* X, int ldx, const float* R, const LmLN* ln, float eps, float* Y, int ldy, int N, hipStream_t st) {
+    constexpr int COLS = (EPI >= 2) ? 256 : 64, KS = (EPI >= 2) ? 4 : 16;      // 1024 threads either way
+    if (W.K % (16 * KS)) return hipErrorInvalidValue;
     if (EPI >= 2 && W.M != 256) return hipErrorInvalidValue;
-    const dim3 grid((W.M + 255) / 256, (N + 7) / 8);
-    hipLaunchKernelGGL(lm_linear_kernel<EPI>, grid, dim3(256), (size_t)W.K * 8 * sizeof(float), st, X, ldx, W.wt, W.b, R, ln ? ln->g : nullptr, ln ? ln->b : nullptr,
-                       eps, Y, ldy, N, W.K, W.M);
+    const dim3 grid((W.M + COLS - 1) / COLS, (N + 7) / 8);
+    const size_t lds = ((size_t)W.K * 8 + (size_t)(KS - 1) * COLS * 8) * sizeof(float);
+    hipLaunchKernelGGL((lm_linear_kernel<EPI, COLS, KS>), grid, dim3(COLS * KS), lds, st, X, ldx, W.wt, W.b, R, ln ? ln->g : nullptr, ln ? ln->b : nullptr, eps, Y,
+                       ldy, N, W.K, W.M);
     return hipGetLastError();
 }
 hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* vc, int cap, int B, int Lq, int Lk, const lds_lm_cfg& c, float* out, hipStream_t st) {
     const int total = B * Lq * c.heads;
-    const size_t lds = (size_t)4 * ((Lk + 63) & ~63) * sizeof(float);
-    hipLaunchKernelGGL(lm_attn_kernel, dim3((total + 3) / 4), dim3(256), lds, st, q, ldq, kc, vc, cap, Lq, Lk, c.hidden, c.heads, total, out);
+    const size_t lds = (size_t)(((Lk + 63) & ~63) + 4 * 34) * sizeof(float);
+    hipLaunchKernelGGL(lm_attn_kernel, dim3(total), dim3(256), lds, st, q, ldq, kc, vc, cap, Lq, Lk, c.hidden, c.heads, out);
     return hipGetLastError();
 }
 // one BERT-style post-LN layer over N = B * L rows; self-attention over [pos0, pos0 + L) appended to the cache (kc, vc)
-int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& w, float* x, float* y, int B, int L, int pos0, float* kc, float* vc, int cap,
+int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& w, float*& x, float*& y, int B, int L, int pos0, float* kc, float* vc, int cap,
              const float* ckc, const float* cvc, int Lenc, hipStream_t st) {
     const lds_lm_cfg& c = lm->cfg;
     const int H = c.hidden, N = B * L;
@@ -513,7 +609,7 @@ int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& 
     }
     LM_HIP(lm_lin<1>(Ly.ff1, cur, H, nullptr, nullptr, c.eps, w.ff, c.inter, N, st));
     LM_HIP(lm_lin<2>(Ly.ff2, w.ff, c.inter, cur, &Ly.ln_ff, c.eps, oth, H, N, st));
-    if (oth != x) LM_HIP(hipMemcpyAsync(x, oth, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));      // result always in x
+    if (oth != x) { float* t = x; x = y; y = t; }      // the result is in `x` on return (the two buffers swap roles)
     return LDS_OK;
 }
 }  // namespace
@@ -540,14 +636,15 @@ extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* to
     if (!A.ok) return lm_fail(LDS_ENOMEM, "LM workspace too small: need %zu bytes", A.used);
     const int N = B * L, H = c.hidden;
     hipLaunchKernelGGL(lm_embed_kernel, dim3(N), dim3(256), 0, st, lm->enc.word, lm->enc.type, lm->spk, lm->enc.ln_emb.g, lm->enc.ln_emb.b, phone, 1, tone,
-                       lm->spk ? spk_id : nullptr, 1, c.eps, H, w.x);
+                       lm->spk ? spk_id : nullptr, 1, c.eps, H, c.text_vocab, c.type_vocab, c.n_spk_rows > 0 ? c.n_spk_rows : 1, w.x);
     LM_HIP(hipGetLastError());
+    float *cx = w.x, *cy = w.y;
     for (const LmLayer& Ly : lm->enc.layers) {
         // the encoder's "cache" is just this layer's keys / values for all L positions
-        int r = lm_layer(lm, lm->enc, Ly, w, w.x, w.y, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, st);
+        int r = lm_layer(lm, lm->enc, Ly, w, cx, cy, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, st);
         if (r != LDS_OK) return r;
     }
-    LM_HIP(hipMemcpyAsync(enc, w.x, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));
+    LM_HIP(hipMemcpyAsync(enc, cx, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));
     return LDS_OK;
 }
 
@@ -591,15 +688,16 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
     for (int step = 0; step + 1 < max_length; ++step) {
         // token at position `step` -> logits -> token at position step + 1
         hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, st, lm->dec.word, lm->dec.type, (const float*)nullptr, lm->dec.ln_emb.g, lm->dec.ln_emb.b,
-                           (const int64_t*)(tokens + step), max_length, (const int64_t*)nullptr, (const int64_t*)nullptr, 0, c.eps, H, w.x);
+                           (const int64_t*)(tokens + step), max_length, (const int64_t*)nullptr, (const int64_t*)nullptr, 0, c.eps, H, c.sem_vocab, 1, 1, w.x);
         LM_HIP(hipGetLastError());
+        float *cx = w.x, *cy = w.y;
         for (int i = 0; i < c.dec_layers; ++i) {
-            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, w.x, w.y, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
+            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, cx, cy, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
             if (r != LDS_OK) return r;
         }
-        LM_HIP(lm_lin<3>(lm->head_t, w.x, H, nullptr, &lm->head_ln, c.eps, w.y, H, B, st));
+        LM_HIP(lm_lin<3>(lm->head_t, cx, H, nullptr, &lm->head_ln, c.eps, cy, H, B, st));
         float* lg = logits_out ? logits_out + (size_t)step * B * V : w.logits;
-        LM_HIP(lm_lin<0>(lm->head_d, w.y, H, nullptr, nullptr, c.eps, lg, V, B, st));
+        LM_HIP(lm_lin<0>(lm->head_d, cy, H, nullptr, nullptr, c.eps, lg, V, B, st));
         hipLaunchKernelGGL(lm_sample_kernel, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
                            do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
         LM_HIP(hipGetLastError());

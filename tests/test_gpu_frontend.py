@@ -196,3 +196,13 @@ def test_roformer_sampling_controls_vs_oracle(lm_gpu):
             nxt.append(int(ids[o][j]))
         seq = np.concatenate([seq, np.array(nxt)[:, None]], axis=1)
     assert np.array_equal(toks.cpu().numpy(), seq[:, : toks.shape[1]])
+
+
+def test_full_tts_path_phones_to_wav(tmp_path):
+    """BASELINE config 5's path in-process: phone / tone ids -> RoFormer sampling -> codebook gather -> Unit2Mel -> vocoder"""
+    sys.path.insert(0, ROOT)
+    import infer_tts
+    ph = np.stack([(np.arange(12) * 7 % 107 + 1), (np.arange(12) * 5 % 12)]).astype(np.int64)
+    np.save(tmp_path / "phones.npy", ph)
+    wav = infer_tts.main(["--synthetic", "--phones", str(tmp_path / "phones.npy"), "--max_length", "17", "-s", "250", "-o", str(tmp_path / "o.npy")])
+    assert wav.shape == (16 * 512,) and np.isfinite(wav).all()      # 17 - BOS tokens (random weights never emit EOS)
