@@ -76,7 +76,8 @@ def _pmc_key(kernel_name):
     if not m:
         return None
     fam, bm, bn, kt, st, up, bk, nst = m.groups()
-    return f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}>" if nst else None
+    # rocprofv3 prints every template argument: <BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC> (the UNet's kernels have DIL 1, VOC false)
+    return f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}, 1, false>" if nst else None
 
 
 def pmc_traffic(kernel_name):
