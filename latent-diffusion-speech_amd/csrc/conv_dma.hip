@@ -746,7 +746,7 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
             if (bk == 16 && nst == 4) DCASE(64, 64, 3, 1, false, 16, 4);
             if (bk == 32 && nst == 4) DCASE(64, 64, 3, 1, false, 32, 4);
         } else if (tk == 32064) {
-            if (bk == 32) DCASE(32, 64, 3, 1, false, 32, 2);
+            if (bk == 32) DCASE(32, 64, 3, 1, false, 32, 2);      // BK 64 and a 3-deep ring measured 0-25 % slower here (tools/bench_dconv.py)
         } else if (tk == 128064) {
             if (bk == 16 && nst == 2) DCASE(128, 64, 3, 1, false, 16, 2);
             if (bk == 16 && nst == 3) DCASE(128, 64, 3, 1, false, 16, 3);
