@@ -215,6 +215,10 @@ int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, c
                           int groups, int silu, float* mid, float* out, int B, int C, int Co, int T, int cfg, void* stream);
 int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
                           float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
+/* one residual step of a vocoder ResBlock1 on the K4P / LDS-DMA path: out = c2(lrelu(c1(lrelu(x)))) + x (reference models.py:186-192);
+ * mode 0 plain output, 1 raw + LeakyReLU'd K4P outputs (returned plain in out / out_act), 2 running sum out = (acc + y) / div */
+int lds_test_voc_step(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil, int mode,
+                      const float* acc, float div, float* out, float* out_act, int B, void* stream);
 /* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
 int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
 int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,

@@ -93,6 +93,24 @@ __global__ void __launch_bounds__(256) from_k4p_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) ob[(long long)(2 * j + hh) * T + t] = v[j];
     }
 }
+// K4P with `pad` frames per side -> plain [B][C][T] (test entry points of the vocoder path)
+__global__ void __launch_bounds__(256) from_k4p_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int pad) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int Tp = T + 2 * pad;
+    const float* ib = in + (((long long)b * (C >> 3) + q) * 2) * Tp * 4;
+    float* ob = out + ((long long)b * C + q * 8) * T;
+    for (int idx = threadIdx.x; idx < 2 * T; idx += 256) {
+        const int hh = idx / T, t = idx - hh * T;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ib + ((long long)hh * Tp + t + pad) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[(long long)(2 * j + hh) * T + t] = v[j];
+    }
+}
+hipError_t launch_from_k4p_pad(const float* in, float* out, int B, int C, int T, int pad, hipStream_t s) {
+    if (C & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(from_k4p_pad_kernel, dim3(C / 8, B), dim3(256), 0, s, in, out, C, T, pad);
+    return hipGetLastError();
+}
 hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hipStream_t s) {
     if (C & 7) return hipErrorInvalidValue;
     hipLaunchKernelGGL(from_k4p_kernel, dim3(C / 8, B), dim3(256), 0, s, in, out, C, T);

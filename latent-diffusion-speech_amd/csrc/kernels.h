@@ -97,6 +97,7 @@ const char* conv_dma_last_config();
 // plain [B][C][T] -> channels [c_off, c_off+C) of a K4P tensor with Ctot channels (pads of those rows zeroed)
 hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s);
 hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hipStream_t s);
+hipError_t launch_from_k4p_pad(const float* in, float* out, int B, int C, int T, int pad, hipStream_t s);
 // plain [B][C][T] -> attention's VT layout [B][C/D][ceil(T/4)][D][4] (tail keys zeroed); the UNet gets this layout straight
 // from the QKV convolution's epilogue, this kernel serves the stand-alone attention entry point
 hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, int D, hipStream_t s);

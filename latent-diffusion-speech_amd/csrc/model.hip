@@ -1631,6 +1631,52 @@ extern "C" int lds_test_ln_chain_k4p(const float* x, const float* w1, const floa
     return LDS_OK;
 }
 
+// One residual step of a vocoder ResBlock1 on the K4P / LDS-DMA path (reference models.py:186-192):
+//   out = c2(lrelu(c1(lrelu(x)))) + x,  c1: k taps with dilation d, c2: k taps with dilation 1, slope 0.1;
+// x plain [B,C,T] -> K4P raw + LeakyReLU'd copies (32 pad frames) -> c1 (activated output) -> c2 (+ residual).  mode 0: plain
+// output; 1: raw K4P output and its LeakyReLU'd twin (returned as out / out_act, converted back); 2: running-sum epilogue
+// out = (acc + y) / div with `acc` = a plain tensor converted to K4P.
+extern "C" int lds_test_voc_step(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil, int mode,
+                                 const float* acc, float div, float* out, float* out_act, int B, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !w1 || !w2 || !out || C % 64 || (K != 3 && K != 7 && K != 11)) return fail(LDS_EINVAL, "bad argument");
+    Owner own;
+    TmpDev tmp;
+    ConvW W1, W2;
+    if (!pack_conv(own, w1, b1, C, C, K, W1) || !pack_conv(own, w2, b2, C, C, K, W2)) return fail(LDS_ENOMEM, "upload failed");
+    const int P = kVocPad;
+    const size_t n = (size_t)B * C * (T + 2 * P) + 4096;
+    float *raw = tmp.f(n), *act = tmp.f(n), *mid = tmp.f(n), *o_raw = tmp.f(n), *o_act = tmp.f(n), *kacc = tmp.f(n);
+    if (!raw || !act || !mid || !o_raw || !o_act || !kacc) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(hipMemsetAsync(mid, 0xff, n * sizeof(float), st));      // NaN fill: pads must be zeroed explicitly, real frames written
+    HIP_TRY(hipMemsetAsync(act, 0xff, n * sizeof(float), st));
+    HIP_TRY(launch_to_k4p_act(x, raw, act, 0.1f, B, C, T, P, st));
+    HIP_TRY(launch_k4p_zero_pads(act, B, C, T, P, st));
+    HIP_TRY(launch_k4p_zero_pads(mid, B, C, T, P, st));
+    DOpt o1;
+    o1.voc = 1; o1.xpad = P; o1.opad = P; o1.dil = dil; o1.pad = (K * dil - dil) / 2; o1.act_slope = 0.1f;
+    LDS_TRY(run_dconv(W1, act, C, nullptr, 0, T, o1, mid, B, st));
+    DOpt o2;
+    o2.voc = 1; o2.xpad = P; o2.opad = P; o2.pad = (K - 1) / 2; o2.res = raw;
+    if (mode == 0) {
+        o2.out_plain = 1;
+        LDS_TRY(run_dconv(W2, mid, C, nullptr, 0, T, o2, out, B, st));
+    } else if (mode == 1) {
+        o2.out_act = o_act; o2.act_slope = 0.1f;
+        LDS_TRY(run_dconv(W2, mid, C, nullptr, 0, T, o2, o_raw, B, st));
+        // K4P (pad 32) -> plain: reuse to_k4p's inverse through a pad-aware copy
+        HIP_TRY(launch_from_k4p_pad(o_raw, out, B, C, T, P, st));
+        if (out_act) HIP_TRY(launch_from_k4p_pad(o_act, out_act, B, C, T, P, st));
+    } else {
+        if (!acc) return fail(LDS_EINVAL, "mode 2 needs acc");
+        HIP_TRY(launch_to_k4p_act(acc, kacc, nullptr, 0.f, B, C, T, P, st));
+        o2.acc_in = kacc; o2.out_div = div; o2.out_plain = 1;
+        LDS_TRY(run_dconv(W2, mid, C, nullptr, 0, T, o2, out, B, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
 extern "C" int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     TmpDev tmp;

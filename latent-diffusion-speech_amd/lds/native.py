@@ -52,7 +52,7 @@ EXPORTS = [
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_lm_create", "lds_lm_destroy", "lds_lm_workspace_bytes", "lds_lm_encode",
     "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
     "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
-    "lds_test_conv_transpose"]
+    "lds_test_conv_transpose", "lds_test_voc_step"]
 
 
 def lib():

@@ -92,6 +92,14 @@ CONV_CASES = {
     "voc_k11_d1_c16": (2, 16, 0, 500, 16, 11, dict(pad=5, act=2, slope=0.1, use_bias=True)),
     "voc_k11_64128": (1, 64, 0, 300, 64, 11, dict(pad=15, dil=3, act=2, slope=0.1, tile=64128)),
     "voc_post_tanh": (2, 16, 0, 300, 1, 7, dict(pad=3, act=2, slope=0.01, epi=2, use_bias=True)),
+    # conv_small (16 channels, v_mfma_f32_16x16x4_f32, register-resident weights): every tap count / dilation, residual, several
+    # 512-frame blocks, a length that is not a multiple of 4 (scalar staging path), a short one
+    "small_k3_d1": (2, 16, 0, 1300, 16, 3, dict(pad=1, act=2, slope=0.1, use_bias=True, use_res=True)),
+    "small_k3_d5": (1, 16, 0, 700, 16, 3, dict(pad=5, dil=5, act=2, slope=0.1, use_bias=True)),
+    "small_k7_d3": (2, 16, 0, 1024, 16, 7, dict(pad=9, dil=3, act=2, slope=0.1, use_bias=True, use_res=True)),
+    "small_k7_d1_odd": (1, 16, 0, 501, 16, 7, dict(pad=3, act=2, slope=0.1, use_bias=True)),
+    "small_k11_d5": (3, 16, 0, 2100, 16, 11, dict(pad=25, dil=5, act=2, slope=0.1, use_bias=True, use_res=True)),
+    "small_k11_d3_short": (1, 16, 0, 40, 16, 11, dict(pad=15, dil=3, use_bias=True)),
 }
 
 
@@ -178,3 +186,36 @@ def test_transpose_and_axpby():
     a, b = U("ax.a", (1000,)), U("ax.b", (1000,))
     z = native.axpby(dev(a), dev(b), 0.25, 3.0).cpu().numpy()
     assert np.allclose(z, 0.25 * a + 3.0 * b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,T,K,dil,mode,B", [(64, 300, 3, 1, 0, 2), (64, 300, 3, 5, 1, 1), (128, 200, 7, 3, 0, 1), (64, 1000, 7, 5, 2, 1), (128, 129, 11, 1, 1, 2),
+                                             (64, 700, 11, 5, 0, 1), (256, 96, 11, 3, 2, 1)])
+def test_vocoder_resblock_step_dma(C, T, K, dil, mode, B):
+    """one residual step of ResBlock1 on the K4P / LDS-DMA vocoder family (dilated k 3 / 7 / 11 windows, 32-frame pads, LeakyReLU /
+    dual-store / running-sum epilogues, plain store), ragged last tiles included, against the numpy oracle"""
+    _need_gpu()
+    from lds import native
+    from oracle import unet1d
+    x = U(f"vs{C}.{T}.{K}.x", (B, C, T), -2, 2)
+    w1 = U(f"vs{C}.{T}.{K}.w1", (C, C, K)) / np.float32(np.sqrt(C * K))
+    w2 = U(f"vs{C}.{T}.{K}.w2", (C, C, K)) / np.float32(np.sqrt(C * K))
+    b1, b2 = U(f"vs{C}.{K}.b1", (C,), -0.3, 0.3), U(f"vs{C}.{K}.b2", (C,), -0.3, 0.3)
+    acc = U(f"vs{C}.{T}.acc", (B, C, T), -1, 1)
+
+    def lrelu(a):
+        return np.where(a >= 0, a, a * np.float32(0.1)).astype(np.float32)
+    xt = unet1d.conv1d(lrelu(x), w1, b1, pad=(K * dil - dil) // 2, dil=dil)
+    y = (unet1d.conv1d(lrelu(xt), w2, b2, pad=(K - 1) // 2) + x).astype(np.float32)
+    out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    out_act = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    dx, dacc = dev(x), dev(acc)
+    native.check(native.lib().lds_test_voc_step(ct.c_void_p(dx.data_ptr()), ct.c_void_p(w1.ctypes.data), ct.c_void_p(b1.ctypes.data), ct.c_void_p(w2.ctypes.data),
+                                                ct.c_void_p(b2.ctypes.data), C, T, K, dil, mode, ct.c_void_p(dacc.data_ptr()), ct.c_float(3.0),
+                                                ct.c_void_p(out.data_ptr()), ct.c_void_p(out_act.data_ptr()), B,
+                                                ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    if mode == 2:
+        y = ((acc + y) / np.float32(3.0)).astype(np.float32)
+    assert relmax(out.cpu().numpy(), y) < 2e-5, relmax(out.cpu().numpy(), y)
+    if mode == 1:
+        assert relmax(out_act.cpu().numpy(), lrelu(y)) < 2e-5
