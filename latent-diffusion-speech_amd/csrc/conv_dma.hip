@@ -110,9 +110,10 @@ struct DmaKernel {
     float lmu[TN], lrs[TN];   // folded input-LayerNorm statistics of this lane's output columns
     // single-tile waves fetch the epilogue's operands at kernel start (16 + 16 registers): the residual entries and the bias
     // rows have landed long before the main loop ends, so the epilogue begins without a memory round trip
-    static constexpr bool EARLY = TM * TN == 1;
-    f32x2 rsv[EARLY ? 8 : 1];
-    float kbv[EARLY ? 16 : 1];
+    // (vocoder tiles too: their K loops run 20-40 us, the 8 residual registers per 32 x 32 tile fit beside the accumulators)
+    static constexpr bool EARLY = TM * TN == 1 || VOC;
+    f32x2 rsv[EARLY ? TM * TN * 8 : 1];
+    float kbv[EARLY ? TM * 16 : 1];
 
     __device__ __forceinline__ DmaKernel(const DmaConvArgs& p_, float* s_) : p(p_), smem(s_) {}
 
@@ -295,17 +296,25 @@ struct DmaKernel {
         return p.res && tile0 < p.plain_from && tile0 < p.Cout && n < p.To;      // the residual is always a K4P tensor
     }
     __device__ __forceinline__ void early_loads() {
-        const int tile0 = m0 + wm * TM * 32, n = t0 + wn * TN * 32 + c;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rsv[e] = f32x2{0.f, 0.f};
-        if (res_tile(tile0, n)) {
-            const int Tpo = p.To + 2 * p.opad;
-            const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
+        for (int i = 0; i < TM; ++i) {
+            const int tile0 = m0 + wm * TM * 32 + i * 32;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rsv[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
+            for (int j = 0; j < TN; ++j) {
+                const int n = t0 + wn * TN * 32 + j * 32 + c;
+                f32x2* rs = rsv + (i * TN + j) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[e] = f32x2{0.f, 0.f};
+                if (res_tile(tile0, n)) {
+                    const int Tpo = p.To + 2 * p.opad;
+                    const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rs[e] = *reinterpret_cast<const f32x2*>(rb + e * Tpo * 4);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kbv[i * 16 + r] = (p.bias && !p.ln_part) ? p.bias[tile0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) kbv[r] = (p.bias && !p.ln_part) ? p.bias[tile0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
     }
 
     __device__ __forceinline__ void mainloop() {
@@ -339,7 +348,11 @@ struct DmaKernel {
         const bool ln = p.ln_part != nullptr;
         if (EARLY && !ln) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][0][r] += kbv[r];
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] += kbv[i * 16 + r];
         } else if (ln || p.bias) {
             float k1[TM][16], k2[TM][16];
 #pragma unroll
@@ -374,20 +387,6 @@ struct DmaKernel {
     // frame-major store of one 32x32 tile: out[b][co][n], co = c0 + local row
     __device__ __forceinline__ void store_plain(float* base, int Cn, int c0, int i, int j, int n) {
         if (n >= p.To) return;
-        if (VOC && p.acc_in) {                 // MRF running sum kept in K4P (same channels / frames / padding as a K4P output would have)
-            const int Tpo = p.To + 2 * p.opad;
-            const float* ab = p.acc_in + (long long)b * Cn * Tpo + k4p_off(c0, n);
-            f32x2 av[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const f32x2*>(ab + e * Tpo * 4);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    acc[0][i][j][4 * g + hh] += av[2 * g + hh][0];
-                    acc[0][i][j][4 * g + 2 + hh] += av[2 * g + hh][1];
-                }
-        }
         float* ob = base + ((long long)b * Cn + c0) * p.To + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -430,7 +429,7 @@ struct DmaKernel {
         f32x2 rv[8];
         if constexpr (EARLY) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rv[e] = rsv[e];
+            for (int e = 0; e < 8; ++e) rv[e] = rsv[(i * TN + j) * 8 + e];
         } else {
             const int Tpo = p.To + 2 * p.opad;
             const float* rb = p.res + (long long)b * k4p_ck() * Tpo + k4p_off(tile0, n);
@@ -446,6 +445,24 @@ struct DmaKernel {
             }
     }
 
+    // phase 2b (vocoder): the MRF running sum, a K4P tensor with the output's channels / frames / padding whatever the output layout is;
+    // its loads for all tiles of the wave are in flight together, before any store
+    __device__ __forceinline__ void add_running_sum(int tile0, int i, int j, int n) {
+        if (n >= p.To) return;
+        const int Tpo = p.To + 2 * p.opad;
+        const float* ab = p.acc_in + (long long)b * (p.out_plain ? p.Cout : k4p_ck()) * Tpo + k4p_off(tile0, n);
+        f32x2 av[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const f32x2*>(ab + e * Tpo * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                acc[0][i][j][4 * g + hh] += av[2 * g + hh][0];
+                acc[0][i][j][4 * g + 2 + hh] += av[2 * g + hh][1];
+            }
+    }
+
     // phase 3: K4P store of one 32x32 tile (+ pad frames, + GroupNorm / LayerNorm partials).  Vocoder epilogues: the running
     // sum of the MRF (acc_in, out_div), LeakyReLU of the value for the next convolution (act_slope; out_act = second tensor
     // when the raw value is needed too, as a residual).
@@ -457,18 +474,6 @@ struct DmaKernel {
         float* ob = p.out + o0;
         if (ok) {
             if constexpr (VOC) {
-            if (p.acc_in) {
-                f32x2 av[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const f32x2*>(p.acc_in + o0 + e * Tpo * 4);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        acc[0][i][j][4 * g + hh] += av[2 * g + hh][0];
-                        acc[0][i][j][4 * g + 2 + hh] += av[2 * g + hh][1];
-                    }
-            }
             if (p.out_div != 1.0f) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
@@ -583,6 +588,17 @@ struct DmaKernel {
                 }
             }
         }
+        if constexpr (VOC) {
+            if (p.acc_in) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int tile0 = tile_ch(i, geglu);
+                        if (tile0 < p.Cout) add_running_sum(tile0, i, j, t0 + wn * TN * 32 + j * 32 + c);
+                    }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (i >= ni) break;
@@ -640,6 +656,13 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
         // BK 16 (a K-step = 16 channels x all taps: 6 / 14 / 22 MFMA groups of 8 per wave), 2 stages (the weight tile of k 11 is 45 KB per stage)
         if (a.stride != 1 || a.ups || a.epi != EPI_NONE || cfg != 0) return hipErrorInvalidValue;
 #define VCASE(KT_, D_) if (a.KT == KT_ && a.dil == D_) return launch_dma_cfg<64, 128, KT_, 1, false, 16, 2, D_, true>(a, s)
+        // one M-block (64 output channels) and 11 taps: a 256-frame tile amortises the 45 KB weight tile over twice the columns
+        // (measured 104 -> 114 TFLOP/s with the residual epilogue; k 3 / k 7 lose 7 % on the wide tile)
+        if (a.Mp == 64 && a.KT == 11 && a.To >= 1024) {
+#define WCASE(D_) if (a.dil == D_) return launch_dma_cfg<64, 256, 11, 1, false, 16, 2, D_, true>(a, s)
+            WCASE(1); WCASE(3); WCASE(5);
+#undef WCASE
+        }
         VCASE(3, 1); VCASE(3, 3); VCASE(3, 5); VCASE(7, 1); VCASE(7, 3); VCASE(7, 5); VCASE(11, 1); VCASE(11, 3); VCASE(11, 5);
 #undef VCASE
         return hipErrorInvalidValue;

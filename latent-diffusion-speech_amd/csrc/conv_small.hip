@@ -171,6 +171,76 @@ static hipError_t launch_small_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- one output channel (the generator's conv_post: 16 -> 1 channels, k 7, LeakyReLU in, tanh out; models.py:218-221) ----
+// 2 FLOP per input byte: a pure stream.  A thread produces 4 consecutive samples from three aligned 16-byte loads per input
+// channel (the window t-4 .. t+7; neighbours' loads overlap and hit L1), weights broadcast from LDS.
+// Per-sample summation order: channel ascending, tap ascending, one fmaf chain.
+template <int KT>
+__global__ void __launch_bounds__(256) conv_mono_kernel(const ConvArgs p) {
+    static_assert(KT == 7, "window of 12 samples = 4 outputs + 6 halo + 2 alignment");
+    __shared__ float wl[64 * KT];
+    const int C = p.Ci, T = p.Tsrc;
+    for (int i = threadIdx.x; i < C * KT; i += 256) {
+        const int ci = i / KT, tap = i - ci * KT;
+        wl[i] = p.w[((((long long)tap * (C / 8) + (ci >> 3)) * 2 + (ci & 1)) * p.Mp + 0) * 4 + ((ci & 7) >> 1)];
+    }
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t >= T) return;
+    const float* xb = p.x1 + (long long)b * C * T;
+    const bool fast = (T & 3) == 0 && t >= 4 && t + 8 <= T;
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    float o[4] = {bias, bias, bias, bias};
+    for (int ci = 0; ci < C; ++ci) {
+        const float* xr = xb + (long long)ci * T;
+        float v[12];
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(xr + t - 4 + 4 * q);
+                v[4 * q] = u[0]; v[4 * q + 1] = u[1]; v[4 * q + 2] = u[2]; v[4 * q + 3] = u[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { const int s = t - 4 + e; v[e] = (s >= 0 && s < T) ? xr[s] : 0.f; }
+        }
+        if (p.act_in == ACT_LRELU) {
+#pragma unroll
+            for (int e = 1; e < 11; ++e) v[e] = (v[e] >= 0.f) ? v[e] : v[e] * p.slope;
+        }
+#pragma unroll
+        for (int tap = 0; tap < KT; ++tap) {
+            const float w = wl[ci * KT + tap];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(w, v[e + tap + 1], o[e]);      // x[t + e + tap - 3]
+        }
+    }
+    if (p.epi == EPI_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]);
+    }
+    float* ob = p.out + (long long)b * T + t;
+    if ((T & 3) == 0) *reinterpret_cast<f32x4*>(ob) = f32x4{o[0], o[1], o[2], o[3]};
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (t + e < T) ob[e] = o[e];
+    }
+}
+
+bool conv_mono_applies(const ConvArgs& a) {
+    return a.Co == 1 && a.Cout == 1 && a.KT == 7 && a.pad == 3 && a.dil == 1 && a.stride == 1 && !a.ups && a.phases == 1 && a.C2 == 0 && a.Ci % 8 == 0 &&
+           a.Ci <= 64 && (a.epi == EPI_NONE || a.epi == EPI_TANH) && !a.bias_bc && !a.res && !a.accum && a.out_div == 1.0f && a.To == a.Tsrc && a.Tout == a.To &&
+           a.xb1 == (long long)a.C1 * a.Tsrc;
+}
+
+hipError_t launch_conv_mono(const ConvArgs& a, hipStream_t s) {
+    if (!conv_mono_applies(a)) return hipErrorInvalidValue;
+    snprintf(g_scfg, sizeof(g_scfg), "C%d KT%d grid %d", a.Ci, a.KT, (a.Tsrc + 1023) / 1024);
+    hipLaunchKernelGGL(conv_mono_kernel<7>, dim3((a.Tsrc + 1023) / 1024, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 bool conv_small_applies(const ConvArgs& a) {
     return a.Ci == 16 && a.Co == a.Ci && a.C2 == 0 && a.stride == 1 && !a.ups && a.phases == 1 && a.epi == EPI_NONE && !a.bias_bc &&
            (a.KT == 3 || a.KT == 7 || a.KT == 11) && (a.dil == 1 || a.dil == 3 || a.dil == 5) && a.pad == (a.KT - 1) * a.dil / 2 && a.To == a.Tsrc &&

@@ -51,6 +51,8 @@ const char* conv_gemm_last_config();
 // registers, plain tensors.  Same ConvArgs semantics (LeakyReLU on the input, bias, residual, running sum, division).
 bool conv_small_applies(const ConvArgs& a);
 hipError_t launch_conv_small(const ConvArgs& a, hipStream_t s);
+bool conv_mono_applies(const ConvArgs& a);      // one output channel, k 7: the generator's conv_post as a stream
+hipError_t launch_conv_mono(const ConvArgs& a, hipStream_t s);
 const char* conv_small_last_config();
 
 // Weight packers (host side): reference layout -> [KT][Ci][Mp]

@@ -326,12 +326,13 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     const double bytes = 4.0 * ((double)B * W.Ci * s.Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.Tout * (o.res ? 2.0 : 1.0));
     hipError_t e;
     {
-        const bool small = o.tile == 0 && conv_small_applies(a);      // narrow vocoder stages: register-resident weights, 16x16x4 MFMA
-        ProfScope ps(st, small ? "conv_small" : "conv_gemm", flops, bytes);
-        e = small ? launch_conv_small(a, st) : launch_conv_gemm(a, o.tile, st);
+        const bool mono = o.tile == 0 && conv_mono_applies(a);        // conv_post: one output channel, a stream
+        const bool small = mono || (o.tile == 0 && conv_small_applies(a));      // narrow vocoder stages: register-resident weights, 16x16x4 MFMA
+        ProfScope ps(st, mono ? "conv_mono" : small ? "conv_small" : "conv_gemm", flops, bytes);
+        e = mono ? launch_conv_mono(a, st) : small ? launch_conv_small(a, st) : launch_conv_gemm(a, o.tile, st);
         if (ps.on) {
             std::string cfgs(small ? conv_small_last_config() : conv_gemm_last_config());   // "BM.. BN.. KT.. S.. U.. grid ..."
-            std::string nm = std::string(small ? "conv_small<" : "conv_gemm<") + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            std::string nm = std::string(mono ? "conv_mono<" : small ? "conv_small<" : "conv_gemm<") + cfgs.substr(0, cfgs.find(" grid")) + ">";
             if (g_prof_level.load(std::memory_order_relaxed) >= 2) {      // per-shape breakdown (bench.py's vocoder leg, tuning sessions)
                 char sh[96];
                 snprintf(sh, sizeof(sh), " Ci%d Co%d K%d d%d To%d%s%s", W.Ci, W.Co, W.K, o.dil, a.To, o.phases > 1 ? " convT" : "", o.res ? " +res" : "");

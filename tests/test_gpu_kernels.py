@@ -92,6 +92,9 @@ CONV_CASES = {
     "voc_k11_d1_c16": (2, 16, 0, 500, 16, 11, dict(pad=5, act=2, slope=0.1, use_bias=True)),
     "voc_k11_64128": (1, 64, 0, 300, 64, 11, dict(pad=15, dil=3, act=2, slope=0.1, tile=64128)),
     "voc_post_tanh": (2, 16, 0, 300, 1, 7, dict(pad=3, act=2, slope=0.01, epi=2, use_bias=True)),
+    "voc_post_tanh_odd": (3, 16, 0, 1027, 1, 7, dict(pad=3, act=2, slope=0.01, epi=2, use_bias=True)),      # conv_mono: scalar tail path
+    "voc_post_32ch_tiny": (1, 32, 0, 8, 1, 7, dict(pad=3, act=2, slope=0.01, epi=2, use_bias=True)),
+    "voc_post_long": (1, 16, 0, 5000, 1, 7, dict(pad=3, act=2, slope=0.01, epi=2)),
     # conv_small (16 channels, v_mfma_f32_16x16x4_f32, register-resident weights): every tap count / dilation, residual, several
     # 512-frame blocks, a length that is not a multiple of 4 (scalar staging path), a short one
     "small_k3_d1": (2, 16, 0, 1300, 16, 3, dict(pad=1, act=2, slope=0.1, use_bias=True, use_res=True)),

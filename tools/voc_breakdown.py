@@ -1,8 +1,7 @@
-"""Per-shape time / TFLOP/s of every vocoder launch (HIP-event profiler, LDS_PROF_SHAPES=1): 16 utterances x 512 frames."""
+"""Per-shape time / TFLOP/s of every vocoder launch (HIP-event profiler at shape detail): 16 utterances x 512 frames."""
 import os
 import sys
 
-os.environ["LDS_PROF_SHAPES"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "latent-diffusion-speech_amd"))
 import torch  # noqa: E402
@@ -16,14 +15,14 @@ voc = Hifi_VAEGAN(None, device="cuda", h=h, state=init_weights.init_state(arch.g
 mel = torch.from_numpy(init_weights.uniform("voc.mel", (B, T, 80), 5, -1, 1)).cuda()
 voc(mel)
 torch.cuda.synchronize()
-native.prof_enable(True)
+native.prof_enable(2)
 voc(mel)
 torch.cuda.synchronize()
 prof = native.prof_summary()
-native.prof_enable(False)
+native.prof_enable(0)
 prof.sort(key=lambda r: -r["ms"])
 tot = sum(r["ms"] for r in prof)
 print(f"total {tot:.1f} ms")
-for r in prof[:60]:
+for r in prof:
     tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["flops"] else 0
     print(f"{r['name']:86s} n={r['count']:3d} {r['ms']:7.2f} ms {100 * r['ms'] / tot:5.1f}% {1e3 * r['ms'] / r['count']:8.1f} us {tf:6.1f} TF")
