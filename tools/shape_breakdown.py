@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from diffusion.unit2mel import Unit2Mel  # noqa: E402
 from lds import init_weights, native  # noqa: E402
 
-B, T = 16, 512
+B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 512
 m = Unit2Mel(1280, 323, 80).to("cuda").eval()
 units = torch.from_numpy(init_weights.uniform("bench.units", (B, T, 1280), 1, -1.7, 1.7)).cuda()
 spk = torch.ones(B, 1, dtype=torch.int64, device="cuda")
