@@ -463,6 +463,26 @@ struct DmaKernel {
             }
     }
 
+    // polyphase ConvTranspose store (vocoder upsamplers): row m = co * phases + phase, column n -> frame n * phases + phase - tpad of
+    // channel co; the raw value goes to `out` and its LeakyReLU to `out_act` (the next resblocks' residual and first input).  A
+    // workgroup's 64 rows x 128 columns cover whole 64-byte lines between them (8 channels x 4 frames per line), written back from L2.
+    __device__ __forceinline__ void store_phases(int tile0, int i, int j, int n) {
+        const int lg = p.ph_log2, Tpo = p.ph_Tout + 2 * p.opad;
+        const long long ob = (long long)b * p.ph_Cout * Tpo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = m >> lg, f = (n << lg) + (m & ((1 << lg) - 1)) - p.ph_tpad;
+            const bool ok = n < p.To && f >= 0 && f < p.ph_Tout && co < p.ph_Cout;
+            const long long off = ob + (long long)(((co >> 3) * 2 + (co & 1)) * Tpo + f + p.opad) * 4 + ((co & 7) >> 1);
+            const float v = acc[0][i][j][r];
+            if (ok) {
+                p.out[off] = v;
+                if (p.out_act) p.out_act[off] = (v >= 0.f) ? v : v * p.act_slope;
+            }
+        }
+    }
+
     // phase 3: K4P store of one 32x32 tile (+ pad frames, + GroupNorm / LayerNorm partials).  Vocoder epilogues: the running
     // sum of the MRF (acc_in, out_div), LeakyReLU of the value for the next convolution (act_slope; out_act = second tensor
     // when the raw value is needed too, as a residual).
@@ -606,6 +626,9 @@ struct DmaKernel {
             for (int j = 0; j < TN; ++j) {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
                 const int tile0 = tile_ch(i, geglu);
+                if constexpr (VOC) {
+                    if (p.ph_Tout) { store_phases(tile0, i, j, n); continue; }
+                }
                 if (p.out_plain) store_plain(p.out, p.Cout, tile0, i, j, n);
                 else if (tile0 >= p.plain_from) {
                     if (p.vt_D) store_vt(tile0 - p.plain_from, i, j, n);
@@ -655,6 +678,12 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
         // vocoder resblock convolutions (k 3 / 7 / 11, dilation 1 / 3 / 5; LeakyReLU / running-sum epilogues): one 64 x 128 tile shape,
         // BK 16 (a K-step = 16 channels x all taps: 6 / 14 / 22 MFMA groups of 8 per wave), 2 stages (the weight tile of k 11 is 45 KB per stage)
         if (a.stride != 1 || a.ups || a.epi != EPI_NONE || cfg != 0) return hipErrorInvalidValue;
+        if (a.ph_Tout) {      // upsampler: 2 taps per phase
+            if (a.KT != 2 || a.dil != 1 || a.pad != 1 || a.res || a.acc_in || a.out_plain || a.out_div != 1.0f || a.ph_log2 < 0 || a.ph_log2 > 4 ||
+                a.ph_Cout << a.ph_log2 != a.Co || a.ph_Cout % 8)
+                return hipErrorInvalidValue;
+            return launch_dma_cfg<64, 128, 2, 1, false, 16, 2, 1, true>(a, s);
+        }
 #define VCASE(KT_, D_) if (a.KT == KT_ && a.dil == D_) return launch_dma_cfg<64, 128, KT_, 1, false, 16, 2, D_, true>(a, s)
         // one M-block (64 output channels) and 11 taps: a 256-frame tile amortises the 45 KB weight tile over twice the columns
         // (measured 104 -> 114 TFLOP/s with the residual epilogue; k 3 / k 7 lose 7 % on the wide tile)
@@ -667,7 +696,7 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
 #undef VCASE
         return hipErrorInvalidValue;
     }
-    if (a.dil != 1 || a.act_slope != 0.f || a.acc_in || a.out_div != 1.0f) return hipErrorInvalidValue;      // vocoder-only features
+    if (a.dil != 1 || a.act_slope != 0.f || a.acc_in || a.out_div != 1.0f || a.ph_Tout) return hipErrorInvalidValue;      // vocoder-only features
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     // The tile shape fixes the order of the K reduction, so it must not depend on the batch size: an utterance's result is then

@@ -88,6 +88,9 @@ struct DmaConvArgs {
     float* out_act;                     // ... written here while `out` keeps the raw value (null: `out` receives the activated value)
     const float* acc_in;                // K4P running sum added before the division: out = (acc_in + y) / out_div
     float out_div;
+    // polyphase ConvTranspose (vocoder upsamplers; weights packed by pack_convT: row m = co * phases + phase, KT = K / stride taps):
+    // column n of row m is output frame n * phases + phase - ph_tpad of channel co, stored to K4P tensors with ph_Tout frames
+    int ph_log2, ph_tpad, ph_Tout, ph_Cout;      // ph_Tout > 0 selects the mode; phases = 1 << ph_log2; ph_Cout = Co / phases
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);

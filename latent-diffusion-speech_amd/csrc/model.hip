@@ -358,6 +358,7 @@ struct DOpt {
     float2* gnpart_out = nullptr;
     int voc = 0, dil = 1, xpad = 1, opad = 1;
     float act_slope = 0.f; float* out_act = nullptr; const float* acc_in = nullptr; float out_div = 1.f;
+    int ph_log2 = 0, ph_tpad = 0, ph_Tout = 0;      // polyphase ConvTranspose output (kernels.h)
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
 };
@@ -375,6 +376,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     a.out2 = o.out2; a.vt_D = o.vt_D; a.lnpart_out = o.lnpart_out; a.gnpart_out = o.gnpart_out;
     a.voc = o.voc; a.dil = o.dil; a.xpad = o.xpad; a.opad = o.opad; a.act_slope = o.act_slope; a.out_act = o.out_act; a.acc_in = o.acc_in; a.out_div = o.out_div;
     a.ln_part = o.ln_part; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.ln_c1 = o.ln_c1; a.ln_c2 = o.ln_c2;
+    a.ph_log2 = o.ph_log2; a.ph_tpad = o.ph_tpad; a.ph_Tout = o.ph_Tout; a.ph_Cout = o.ph_Tout ? (W.Co >> o.ph_log2) : 0;
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
     a.To = (Tin + 2 * o.pad - o.dil * (W.K - 1) - 1) / o.stride + 1;
     a.B = B;
@@ -389,7 +391,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
             std::string nm = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
             if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
                 char sh[96];
-                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "", o.acc_in ? " +acc" : "");
+                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s%s%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "", o.acc_in ? " +acc" : "", o.ph_Tout ? " convT" : "");
                 nm += sh;
             }
             ps.rename(nm);
@@ -1255,7 +1257,7 @@ extern "C" void lds_vocoder_destroy(lds_vocoder* v) { delete v; }
 // tensor by the producer's epilogue, and the MRF's running sum is accumulated in K4P.  Narrower stages (the 32 / 16-channel
 // tail) and the transposed convolutions stay on the register-staged conv_gemm over plain tensors.
 constexpr int kVocPad = 32;
-struct VocWs { float *x, *xs, *ta, *ra, *rb; float *kx_raw, *kx_act, *kt_act, *ka_raw, *ka_act, *kb_raw, *kb_act, *ks; };
+struct VocWs { float *x, *xs, *ta, *ra, *rb; float *kx_raw, *kx_act, *kt_act, *ka_raw, *ka_act, *kb_raw, *kb_act, *ks, *kin; };
 static bool voc_dma_stage(const lds_vocoder* v, int ch) {
     if (ch % 64) return false;
     for (const VocRes& rb : v->rbs)
@@ -1263,10 +1265,17 @@ static bool voc_dma_stage(const lds_vocoder* v, int ch) {
             if ((rb.k * d - d) / 2 > kVocPad || (d != 1 && d != 3 && d != 5)) return false;
     return true;
 }
+// the upsampler in front of a DMA stage runs on conv_dma too (polyphase rows, 2 taps per phase, power-of-two rate) and writes the
+// stage's K4P tensors directly; its input is the previous stage's MRF output kept in K4P with LeakyReLU applied (VocWs::kin)
+static bool voc_dma_ups(const lds_vocoder* v, int i) {
+    const int s = v->cfg.upsample_rates[i], ch = v->cfg.upsample_initial_channel >> (i + 1);
+    return voc_dma_stage(v, ch) && v->ups[i].K == 2 && (s & (s - 1)) == 0 && s <= 16 && v->ups[i].Mp == v->ups[i].Co && (2 * ch) % 16 == 0;
+}
 static void plan_voc(const lds_vocoder* v, Arena& A, int B, int T, VocWs& w) {
     size_t mx = (size_t)v->cfg.upsample_initial_channel * T, mk = 0;
     int Tl = T;
     for (int i = 0; i < v->cfg.n_ups; ++i) {
+        if (voc_dma_ups(v, i)) mk = std::max(mk, (size_t)(v->cfg.upsample_initial_channel >> i) * (Tl + 2 * kVocPad));      // kin
         Tl *= v->cfg.upsample_rates[i];
         const int ch = v->cfg.upsample_initial_channel >> (i + 1);
         const size_t ct = (size_t)ch * Tl;
@@ -1274,7 +1283,7 @@ static void plan_voc(const lds_vocoder* v, Arena& A, int B, int T, VocWs& w) {
         if (voc_dma_stage(v, ch)) mk = std::max(mk, (size_t)ch * (Tl + 2 * kVocPad));
     }
     w.x = A.f(B * mx); w.xs = A.f(B * mx); w.ta = A.f(B * mx); w.ra = A.f(B * mx); w.rb = A.f(B * mx);
-    float** kb[8] = {&w.kx_raw, &w.kx_act, &w.kt_act, &w.ka_raw, &w.ka_act, &w.kb_raw, &w.kb_act, &w.ks};
+    float** kb[9] = {&w.kx_raw, &w.kx_act, &w.kt_act, &w.ka_raw, &w.ka_act, &w.kb_raw, &w.kb_act, &w.ks, &w.kin};
     for (float** pp : kb) *pp = mk ? A.f(B * mk + 4096) : nullptr;
 }
 extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out) {
@@ -1286,13 +1295,16 @@ extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, s
     return LDS_OK;
 }
 
-// MRF of one stage on the K4P / LDS-DMA path (reference models.py:161-222,250-259): x plain [B][ch][Tl] -> xs plain = mean_j resblock_j(x)
+// MRF of one stage on the K4P / LDS-DMA path (reference models.py:161-222,250-259): x plain [B][ch][Tl] (null: the upsampler has
+// already written kx_raw / kx_act) -> mean_j resblock_j(x), to xs plain, or (xs null) as LeakyReLU(0.1)(.) to the K4P tensor kin,
+// the next upsampler's input
 static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const float* x, float* xs, int ch, int Tl, int B, hipStream_t st) {
     const lds_vocoder_cfg& c = v->cfg;
     const int P = kVocPad;
-    HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kx_act, 0.1f, B, ch, Tl, P, st));
+    if (x) HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kx_act, 0.1f, B, ch, Tl, P, st));
     float* acts[4] = {w.kx_act, w.kt_act, w.ka_act, w.kb_act};
     for (float* a : acts) HIP_TRY(launch_k4p_zero_pads(a, B, ch, Tl, P, st));      // the epilogues below store real frames only
+    if (!xs) HIP_TRY(launch_k4p_zero_pads(w.kin, B, ch, Tl, P, st));
     for (int j = 0; j < c.n_kernels; ++j) {
         const VocRes& rb = v->rbs[stage * c.n_kernels + j];
         const float* cur_raw = w.kx_raw;
@@ -1321,8 +1333,10 @@ static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const fl
                 dst = nraw[m & 1]; o2.out_act = nact[m & 1]; o2.act_slope = 0.1f;
             } else if (j < c.n_kernels - 1) {          // xs (+)= resblock_j(x), kept in K4P
                 dst = w.ks; o2.acc_in = (j > 0) ? w.ks : nullptr;
-            } else {                                   // xs = (xs + resblock_j(x)) / n_kernels, back in the plain layout
+            } else if (xs) {                           // xs = (xs + resblock_j(x)) / n_kernels, back in the plain layout
                 dst = xs; o2.out_plain = 1; o2.acc_in = (j > 0) ? w.ks : nullptr; o2.out_div = (float)c.n_kernels;
+            } else {                                   // ... or LeakyReLU'd in K4P for the next upsampler
+                dst = w.kin; o2.acc_in = (j > 0) ? w.ks : nullptr; o2.out_div = (float)c.n_kernels; o2.act_slope = 0.1f;
             }
             LDS_TRY(run_dconv(*W2, in2, ch, nullptr, 0, Tl, o2, dst, B, st));
             cur_raw = nraw[m & 1]; cur_act = nact[m & 1];
@@ -1350,9 +1364,29 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
     int ch = c.upsample_initial_channel, Tl = T;
     float* x = w.x;
     float* xs = w.xs;
+    bool k4p_in = false;      // the current tensor lives in w.kin (K4P, LeakyReLU applied) instead of x
     for (int i = 0; i < c.n_ups; ++i) {
         const int s_ = c.upsample_rates[i], k = c.upsample_kernel_sizes[i], cout = ch / 2;
         const int Tn = (Tl - 1) * s_ - 2 * ((k - s_ + 1) / 2) + k;
+        const bool k4p_next = i + 1 < c.n_ups && voc_dma_ups(v, i + 1);      // this stage's output feeds a DMA upsampler
+        if (voc_dma_ups(v, i)) {
+            // x = ups[i](leaky_relu(x, 0.1)) on conv_dma: K4P in (kin), the stage's kx_raw / kx_act out
+            if (!k4p_in) {
+                HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kin, 0.1f, B, ch, Tl, kVocPad, st));      // (kx_raw: scratch for the unused raw copy)
+                HIP_TRY(launch_k4p_zero_pads(w.kin, B, ch, Tl, kVocPad, st));
+            }
+            int lg = 0;
+            while ((1 << lg) < s_) ++lg;
+            DOpt o;
+            o.voc = 1; o.xpad = kVocPad; o.opad = kVocPad; o.pad = 1; o.act_slope = 0.1f; o.out_act = w.kx_act;
+            o.ph_log2 = lg; o.ph_tpad = (k - s_ + 1) / 2; o.ph_Tout = Tn;
+            LDS_TRY(run_dconv(v->ups[i], w.kin, ch, nullptr, 0, Tl, o, w.kx_raw, B, st));
+            ch = cout; Tl = Tn;
+            LDS_TRY(voc_mrf_dma(v, w, i, nullptr, k4p_next ? nullptr : xs, ch, Tl, B, st));
+            if (!k4p_next) { float* t = x; x = xs; xs = t; }
+            k4p_in = k4p_next;
+            continue;
+        }
         {
             // x = ups[i](leaky_relu(x, 0.1)) as a polyphase conv
             Src s{x, ch, nullptr, 0, Tl};
