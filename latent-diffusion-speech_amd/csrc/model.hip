@@ -1255,7 +1255,7 @@ extern "C" void lds_vocoder_destroy(lds_vocoder* v) { delete v; }
 // Stages whose width is a multiple of 64 run on the DMA-fed K4P kernel (conv_dma): the tensors between the resblock convolutions
 // live in K4P with kVocPad zero frames per side (the dilated k 7 / 11 taps reach 25 frames out), LeakyReLU is applied once per
 // tensor by the producer's epilogue, and the MRF's running sum is accumulated in K4P.  Narrower stages (the 32 / 16-channel
-// tail) and the transposed convolutions stay on the register-staged conv_gemm over plain tensors.
+// tail) and their upsamplers stay on the register-staged conv_gemm / conv_small over plain tensors.
 constexpr int kVocPad = 32;
 struct VocWs { float *x, *xs, *ta, *ra, *rb; float *kx_raw, *kx_act, *kt_act, *ka_raw, *ka_act, *kb_raw, *kb_act, *ks, *kin; };
 static bool voc_dma_stage(const lds_vocoder* v, int ch) {

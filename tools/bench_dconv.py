@@ -37,6 +37,10 @@ SHAPES = {
     "conv3_1024->512@64": (1024, 0, 64, 512, 3, dict(pad=1)),
     "sc_512+512->512@64": (512, 512, 64, 512, 1, dict()),
     "qkv_512@64": (512, 0, 64, 1536, 1, dict(v_split=1)),
+    "o_512@64": (512, 0, 64, 512, 1, dict(res=True)),
+    "ff2_512@64": (2560, 0, 64, 512, 1, dict(res=True)),
+    "ff2c_512@128": (2560, 0, 128, 512, 1, dict(res=True)),
+    "ff2c_384@256": (1920, 0, 256, 384, 1, dict(res=True)),
 }
 
 
