@@ -263,6 +263,9 @@ class GaussianDiffusion(nn.Module):
         x = x.reshape(b, self.out_dims, -1).contiguous()
         unet = self.denoise_fn.native()
         if method is not None and infer_speedup > 1:
+            if method in ("dpm-solver", "unipc"):
+                # multistep order 2: the reference solvers assert this (dpm_solver_pytorch.py:1172, uni_pc.py:607)
+                assert t // infer_speedup >= 2, f"steps = {t} // {infer_speedup} must be >= order 2"
             if method == "dpm-solver":
                 unet.sample("dpm-solver", self._table(("dpm", t, infer_speedup), lambda: dpm_table(self._buf("betas")[:t], t // infer_speedup)), cond, x)
             elif method == "unipc":

@@ -72,6 +72,9 @@ def test_pndm_batch_gt1_raises_like_reference(unit2mel_gpu):
         gd(torch.zeros(2, 16, 256, device="cuda"), infer=True, infer_speedup=100, method="pndm")
     with pytest.raises(NotImplementedError):
         gd(torch.zeros(1, 16, 256, device="cuda"), infer=True, infer_speedup=100, method="bogus")
+    for method in ("dpm-solver", "unipc"):      # 1000 // 600 = 1 step < order 2: the reference's multistep solvers assert
+        with pytest.raises(AssertionError):
+            gd(torch.zeros(1, 16, 256, device="cuda"), infer=True, infer_speedup=600, method=method)
 
 
 def test_vocoder_vs_reference(golden):
@@ -238,6 +241,24 @@ def test_vocoder_full_size_vs_oracle():
     ref = o_voc.generator_forward(o_voc.fold_weight_norm(state), h, np.ascontiguousarray(z.transpose(0, 2, 1)))
     assert wav.shape == ref.shape == (1, 1, 65536)
     assert relmax(wav, ref) < 1e-4, relmax(wav, ref)
+
+
+def test_vocoder_ragged_batch_vs_oracle():
+    """2 utterances x 37 frames: every stage ends in a partial tile (37*8 = 296 columns ... 18,944 samples), the polyphase
+    upsamplers scatter across utterance boundaries of the K4P tensors, and the batch index enters every address."""
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights
+    from oracle import vocoder as o_voc
+    h = arch.SYNTHETIC_VOCODER_H
+    state = init_weights.init_state(arch.generator_param_shapes(h), 0)
+    voc = Hifi_VAEGAN(None, device="cuda", h=h, state=state)
+    z = init_weights.uniform("ragged.voc.z", (2, 37, 80), 43, -1.5, 1.5)
+    wav = voc(dev(z)).cpu().numpy()
+    ref = o_voc.generator_forward(o_voc.fold_weight_norm(state), h, np.ascontiguousarray(z.transpose(0, 2, 1)))
+    assert wav.shape == ref.shape == (2, 1, 37 * 512)
+    assert relmax(wav, ref) < 1e-4, relmax(wav, ref)
+    one = voc(dev(z[1:2])).cpu().numpy()      # an utterance alone = inside the batch
+    assert np.array_equal(one[0], wav[1])
 
 
 def test_parent_load_state_dict_repacks_weights(unit2mel_gpu):
