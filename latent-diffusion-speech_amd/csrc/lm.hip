@@ -321,6 +321,9 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* lg = logits + (long long)b * V;
     int64_t* seq = tokens + (long long)b * cap_tokens;
+    // thread 0 needs these at the very end: fetched now, their latency hides behind the top-k rounds
+    const float u_draw = (tid == 0 && do_sample) ? uniforms[b] : 0.f;
+    const int alive = (tid == 0) ? unfinished[b] : 0;
     float v[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
                 while (q >= 0 && topi[ord[q]] > topi[o]) { ord[q + 1] = ord[q]; --q; }
                 ord[q + 1] = o;
             }
-            const float u = uniforms[b];
+            const float u = u_draw;
             float c = 0.f;
             next = topi[ord[kept - 1]];
             for (int j = 0; j < kept; ++j) {
@@ -411,7 +414,6 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
             }
         }
         if (next < 0 || next >= V) next = pad;                          // all-NaN logits: nothing compares greater than -inf
-        const int alive = unfinished[b];
         if (!alive) next = pad;
         seq[step + 1] = next;
         if (alive && next == eos) unfinished[b] = 0;
