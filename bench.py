@@ -157,7 +157,7 @@ def roofline_from_profile(prof):
 def timed_loop(step, steps, warmup, world, sync, dist=None, dev=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync; max over ranks."""
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         sync()
 
@@ -170,7 +170,7 @@ def timed_loop(step, steps, warmup, world, sync, dist=None, dev=None):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -190,14 +190,15 @@ def run_job(args, rank, world, dev, model, voc=None, dist=None, sync=None, profi
         units_all, spk_all = make_inputs(world * B, T)
     else:
         units_all = spk_all = torch.empty(0, device=dev)
-    units = shard.scatter_batch(units_all, rank, world, shape=(world * B, T, 1280), dtype=torch.float32, device=dev)
-    spk = shard.scatter_batch(spk_all, rank, world, shape=(world * B, 1), dtype=torch.int64, device=dev)
+    force = dist is not None      # (--rehearse-rccl: the collectives run even at N = 1)
+    units = shard.scatter_batch(units_all, rank, world, shape=(world * B, T, 1280), dtype=torch.float32, device=dev, force=force)
+    spk = shard.scatter_batch(spk_all, rank, world, shape=(world * B, 1), dtype=torch.int64, device=dev, force=force)
     del units_all
 
     def step(gather=True):
         mel = model(units, None, spk_id=spk, infer=True, infer_speedup=speedup, method=args.method)
         wav = voc(mel) if voc is not None else None
-        out = shard.gather_batch(mel, rank, world, sizes=[B] * world) if gather else mel
+        out = shard.gather_batch(mel, rank, world, sizes=[B] * world, force=force) if gather else mel
         return out, wav
 
     dt, (out, wav) = timed_loop(step, args.steps, args.warmup, world, sync, dist, dev)
@@ -351,6 +352,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-nfe", type=int, default=8)
     ap.add_argument("--vocoder", action="store_true", help="run the HiFi-VAEGAN decode inside the timed step (BASELINE config 4)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (configs[3], UniPC-20, B=1 latency) at N=1")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="N=1 only: open a single-rank RCCL process group and issue every collective of the N>1 path (scatter, gather, barrier, all-reduce)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented roofline step (for rocprofv3 --pmc passes)")
     return ap.parse_args(argv)
 
@@ -371,8 +374,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.rehearse_rccl:
         import torch.distributed as dist
+        if world == 1:      # one-GPU rehearsal of the N > 1 branch: a single-rank RCCL group, every collective of the job still issued
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from diffusion.unit2mel import Unit2Mel
@@ -400,7 +406,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_nfe)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,12 +24,13 @@ def _meta(full, rank, src, shape, dtype):
     return tuple(box[0][0]), box[0][1]
 
 
-def scatter_batch(full, rank, world, src=0, shape=None, dtype=None, device=None):
+def scatter_batch(full, rank, world, src=0, shape=None, dtype=None, device=None, force=False):
     """Rank `src` holds `full` [N, ...]; every rank returns its shard [n_r, ...] (contiguous balanced split).
     One scatter: each rank receives only its own rows (42 MB of units per rank at B=16 x 512 frames, instead of the
     whole batch).  Ragged splits pad every shard to the largest one.  `shape` / `dtype` = those of the full batch when
-    every rank knows them (saves the object broadcast); `device` = where non-src ranks allocate (default: full.device)."""
-    if world == 1:
+    every rank knows them (saves the object broadcast); `device` = where non-src ranks allocate (default: full.device).
+    `force` runs the collective even for a single rank (a one-GPU rehearsal of the RCCL call pattern)."""
+    if world == 1 and not force:
         return full
     shp, dt = _meta(full, rank, src, shape, dtype)
     dev = device if device is not None else full.device
@@ -52,10 +53,10 @@ def scatter_batch(full, rank, world, src=0, shape=None, dtype=None, device=None)
     return recv[: hi - lo].contiguous() if hi - lo < mx else recv
 
 
-def gather_batch(local, rank, world, dst=0, sizes=None):
+def gather_batch(local, rank, world, dst=0, sizes=None, force=False):
     """Concatenate per-rank results [n_r, ...] on rank `dst` (None elsewhere): one gather to `dst`.
     `sizes` = the per-rank n_r when the caller knows them (saves the object collective and its host synchronisation)."""
-    if world == 1:
+    if world == 1 and not force:
         return local
     if sizes is None:
         sizes = [None] * world
