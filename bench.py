@@ -336,6 +336,25 @@ def extra_legs(args, dev, model, make_inputs):
         "ms_per_step": 1e3 * dt, "x_realtime": Bq * T * FRAME_SEC / dt, "rtf": dt / (Bq * T * FRAME_SEC),
         "lm_ms": 1e3 * dt_lm, "lm_tokens_per_sec": Bq * T / dt_lm, "lm_us_per_decode_step": 1e6 * dt_lm / T,
     }
+    # ---- the 22_infer_tts.py caller itself: ONE utterance, phones -> tokens -> units -> mel -> wav ----
+    p1, t1 = phones[:1].contiguous(), tones[:1].contiguous()
+
+    def lm_one():
+        keep["tok1"] = infer_tts.text2semantic(lm, p1, t1, 1, T + 1)
+
+    def full_one():
+        lm_one()
+        units = native.gather_rows(codebook, keep["tok1"].clamp(max=4095))
+        mel = model(units, None, spk_id=spk[:1], infer=True, infer_speedup=1000 // args.nfe, method=args.method)
+        keep["wav1"] = voc(mel)
+    dt_lm1 = timeit(lm_one, 2)
+    dt1 = timeit(full_one, 2)
+    assert tuple(keep["tok1"].shape) == (1, T) and bool(torch.isfinite(keep["wav1"]).all())
+    extra["b1_full_tts_latency"] = {
+        "workload": f"1 utterance: {Lp} phones -> {T} sampled tokens -> {args.nfe}-step {args.method} -> {T * 512} samples (22_infer_tts.py, one sentence)",
+        "ms_per_utterance": 1e3 * dt1, "audio_seconds": T * FRAME_SEC, "x_realtime": T * FRAME_SEC / dt1, "rtf": dt1 / (T * FRAME_SEC),
+        "lm_ms": 1e3 * dt_lm1, "lm_us_per_decode_step": 1e6 * dt_lm1 / T,
+    }
     return extra
 
 
