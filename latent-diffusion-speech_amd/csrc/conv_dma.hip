@@ -641,7 +641,8 @@ struct DmaKernel {
 };
 
 template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
-__global__ void __launch_bounds__(256, (DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>::OCC)) conv_dma_kernel(const DmaConvArgs p) {
+// (the polyphase upsampler's scatter epilogue needs more than the 128 registers of 4 workgroups per CU: 2 per CU, no spills)
+__global__ void __launch_bounds__(256, ((VOC && KT == 2) ? 2 : DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>::OCC)) conv_dma_kernel(const DmaConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC> k(p, smem);
     k.setup();

@@ -54,13 +54,16 @@ static __device__ __forceinline__ void block_sum8(float (&v)[8], float* red8) {
         for (int j = 0; j < 8; ++j) red8[(threadIdx.x >> 6) * 8 + j] = v[j];
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < NT / 64; ++i) t += red8[i * 8 + j];
-        v[j] = t;
+    // (two 16-byte reads per wave slot, four slots in flight: fully unrolled scalar reads keep 128 values live and spill)
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = 0; i < NT / 64; ++i) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(red8 + i * 8), b = *reinterpret_cast<const f32x4*>(red8 + i * 8 + 4);
+        t[0] += a[0]; t[1] += a[1]; t[2] += a[2]; t[3] += a[3];
+        t[4] += b[0]; t[5] += b[1]; t[6] += b[2]; t[7] += b[3];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = t[j];
 }
 static __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum(v);
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __res
                                                              const float* __restrict__ R, const float* __restrict__ g, const float* __restrict__ bta, float eps,
                                                              float* __restrict__ Y, int ldy, int N, int K, int M) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // xs [K][8] then part [KS-1][COLS][8]
-    __shared__ float red8[16 * 8];
+    __shared__ __attribute__((aligned(16))) float red8[16 * 8];
     float* xs = sm;
     float* part = sm + (size_t)K * 8;
     const int tid = threadIdx.x, col = tid % COLS, ks = tid / COLS;
@@ -167,10 +170,22 @@ __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __res
         }
         return;
     }
+    // five slices (40 partials) in flight at a time: all 120 at once do not fit beside the rest in the 128 registers of a 1024-thread
+    // workgroup and spill
+    constexpr int QC = (KS - 1) % 5 == 0 ? 5 : 3;
+    static_assert((KS - 1) % QC == 0, "K slices per workgroup: 4 or 16");
+#pragma unroll 1
+    for (int q0 = 0; q0 < KS - 1; q0 += QC) {
+        float t[QC][8];
 #pragma unroll
-    for (int q = 0; q < KS - 1; ++q)
+        for (int q = 0; q < QC; ++q)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += part[(q * COLS + col) * 8 + j];
+            for (int j = 0; j < 8; ++j) t[q][j] = part[((q0 + q) * COLS + col) * 8 + j];
+#pragma unroll
+        for (int q = 0; q < QC; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += t[q][j];
+    }
     const float bm = (m < M && bias) ? bias[m] : 0.f;
     float y[8];
     bool ok[8];
