@@ -21,15 +21,40 @@ namespace lds {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave64 reductions on the DPP path (row shifts + row broadcasts: VALU speed, no LDS crossbar), result in every lane.  A butterfly of
+// __shfl_xor is six dependent ds_bpermute round trips (~0.3 us); the decode step runs ~40 of these reductions back to back.
+template <int CTRL, int ROW_MASK, bool BOUND>
+static __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, BOUND); }
+template <int CTRL, int ROW_MASK, bool BOUND>
+static __device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
 }
-static __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+static __device__ __forceinline__ float wave_sum(float v) {      // fixed order; the total forms in lane 63
+    v += dpp_f<0x111, 0xf, true>(0.f, v);      // row_shr:1
+    v += dpp_f<0x112, 0xf, true>(0.f, v);      // row_shr:2
+    v += dpp_f<0x114, 0xf, true>(0.f, v);      // row_shr:4
+    v += dpp_f<0x118, 0xf, true>(0.f, v);      // row_shr:8: lane 15 of every 16-lane row = the row's sum
+    v += dpp_f<0x142, 0xa, false>(0.f, v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_f<0x143, 0xc, false>(0.f, v);     // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+static __device__ __forceinline__ float wave_max(float v) {      // lanes without a source keep their own value (old = v)
+    v = fmaxf(v, dpp_f<0x111, 0xf, false>(v, v));
+    v = fmaxf(v, dpp_f<0x112, 0xf, false>(v, v));
+    v = fmaxf(v, dpp_f<0x114, 0xf, false>(v, v));
+    v = fmaxf(v, dpp_f<0x118, 0xf, false>(v, v));
+    v = fmaxf(v, dpp_f<0x142, 0xa, false>(v, v));
+    v = fmaxf(v, dpp_f<0x143, 0xc, false>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+static __device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<0x111, 0xf, false>(v, v));
+    v = min(v, dpp_i<0x112, 0xf, false>(v, v));
+    v = min(v, dpp_i<0x114, 0xf, false>(v, v));
+    v = min(v, dpp_i<0x118, 0xf, false>(v, v));
+    v = min(v, dpp_i<0x142, 0xa, false>(v, v));
+    v = min(v, dpp_i<0x143, 0xc, false>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 // sum over the NT threads of a workgroup (fixed order), result in every thread; red has NT / 64 <= 16 slots
 template <int NT>
@@ -326,6 +351,7 @@ __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ 
 //      softmax + one draw; greedy = argmax).  The draw is the inverse-CDF rule over the vocabulary order with a caller-supplied
 //      uniform (torch.multinomial's own stream cannot be reproduced outside torch).  One workgroup per sequence, V <= 256 * 32. ----
 constexpr int kMaxTopK = 64;
+template <int NI>      // NI * 256 >= V: vocabulary slots per thread
 __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict__ logits, int V, int do_sample, int top_k, float top_p, float inv_temp,
                                                         float rep_pen, const float* __restrict__ uniforms, int64_t* __restrict__ tokens, int cap_tokens,
                                                         int step, int* __restrict__ unfinished, int eos, int pad, int* __restrict__ any_unfinished) {
@@ -339,9 +365,9 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
     // thread 0 needs these at the very end: fetched now, their latency hides behind the top-k rounds
     const float u_draw = (tid == 0 && do_sample) ? uniforms[b] : 0.f;
     const int alive = (tid == 0) ? unfinished[b] : 0;
-    float v[32];
+    float v[NI];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = tid + 256 * i;
         v[i] = (c < V) ? lg[c] : -INFINITY;
     }
@@ -352,29 +378,28 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
             if ((t & 255) == tid && !((done >> (t >> 8)) & 1u)) {
                 done |= 1u << (t >> 8);
 #pragma unroll
-                for (int i = 0; i < 32; ++i)
+                for (int i = 0; i < NI; ++i)
                     if (i == (t >> 8)) v[i] = (v[i] < 0.f) ? v[i] * rep_pen : v[i] / rep_pen;
             }
         }
     }
     if (do_sample && inv_temp != 1.0f) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) v[i] *= inv_temp;
+        for (int i = 0; i < NI; ++i) v[i] *= inv_temp;
     }
     const int rounds = do_sample ? top_k : 1;
     for (int r = 0; r < rounds; ++r) {      // r-th largest remaining value, ties to the lowest index
         float bv = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int c = tid + 256 * i;
             if (v[i] > bv || (v[i] == bv && c < bi && v[i] > -INFINITY)) { bv = v[i]; bi = c; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        {   // wave argmax: the largest value, then the lowest index among the lanes that hold it (NaNs never win)
+            const float m = wave_max(bv);
+            bi = wave_min_i((bv == m) ? bi : 0x7fffffff);
+            bv = m;
         }
         __syncthreads();
         if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
@@ -386,7 +411,7 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
         if (tid == 0) { topv[r] = bv; topi[r] = bi; }
         if ((bi & 255) == tid) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i)
+            for (int i = 0; i < NI; ++i)
                 if (i == (bi >> 8)) v[i] = -INFINITY;
         }
     }
@@ -715,8 +740,12 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
         LM_HIP(lm_lin<3>(lm->head_t, cx, H, nullptr, &lm->head_ln, c.eps, cy, H, B, st));
         float* lg = logits_out ? logits_out + (size_t)step * B * V : w.logits;
         LM_HIP(lm_lin<0>(lm->head_d, cy, H, nullptr, nullptr, c.eps, lg, V, B, st));
-        hipLaunchKernelGGL(lm_sample_kernel, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
-                           do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+        if (V <= 256 * 9)
+            hipLaunchKernelGGL(lm_sample_kernel<9>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
+                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+        else
+            hipLaunchKernelGGL(lm_sample_kernel<32>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
+                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
         LM_HIP(hipGetLastError());
         // EOS poll every 8 steps: the loop ends after the step in which the last running sequence emitted EOS
         if ((step & 7) == 7 || step + 2 == max_length) {
