@@ -303,9 +303,18 @@ __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ 
         float dot = -INFINITY;
         if (key < Lk) {
             dot = 0.f;
+            if (d == 32) {      // the key row as eight 16-byte loads (a lane per key: every load instruction gathers 64 rows)
+                const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)key * 32);
+                f32x4 kv[8];
 #pragma unroll
-            for (int e = 0; e < 32; ++e)
-                if (e < d) dot = fmaf(qr[e], kb[(long long)key * d + e], dot);
+                for (int e4 = 0; e4 < 8; ++e4) kv[e4] = kr[e4];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) dot = fmaf(qr[e], kv[e >> 2][e & 3], dot);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 32; ++e)
+                    if (e < d) dot = fmaf(qr[e], kb[(long long)key * d + e], dot);
+            }
             dot *= scale;
         }
         sc[key] = dot;
@@ -328,6 +337,7 @@ __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ 
     if (e < d && mx > -INFINITY)
         for (int k0 = wave * 64; k0 < Lk; k0 += 256) {
             const int kend = (k0 + 64 < Lk) ? k0 + 64 : Lk;
+#pragma unroll 8
             for (int key = k0 + half; key < kend; key += 2) acc = fmaf(sc[key], vb[(long long)key * d + e], acc);
         }
     acc += __shfl_xor(acc, 32, 64);
