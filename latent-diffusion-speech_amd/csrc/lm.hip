@@ -753,6 +753,9 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
         if (V <= 256 * 9)
             hipLaunchKernelGGL(lm_sample_kernel<9>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
                                do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+        else if (V <= 256 * 17)      // (the reference's 4096-entry semantic codebook + 3 special ids)
+            hipLaunchKernelGGL(lm_sample_kernel<17>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
+                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
         else
             hipLaunchKernelGGL(lm_sample_kernel<32>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
                                do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
