@@ -364,9 +364,12 @@ constexpr int kMaxTopK = 64;
 template <int NI>      // NI * 256 >= V: vocabulary slots per thread
 __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict__ logits, int V, int do_sample, int top_k, float top_p, float inv_temp,
                                                         float rep_pen, const float* __restrict__ uniforms, int64_t* __restrict__ tokens, int cap_tokens,
-                                                        int step, int* __restrict__ unfinished, int eos, int pad, int* __restrict__ any_unfinished) {
+                                                        int step, int* __restrict__ unfinished, int eos, int pad, int* __restrict__ any_unfinished,
+                                                        const float* __restrict__ word, const float* __restrict__ type, const float* __restrict__ eg,
+                                                        const float* __restrict__ eb, float eps, int H, float* __restrict__ xnext) {
     __shared__ float rv[4];
     __shared__ int ri[4];
+    __shared__ int chosen;
     __shared__ float topv[kMaxTopK], pr[kMaxTopK];
     __shared__ int topi[kMaxTopK], ord[kMaxTopK];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -466,8 +469,33 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
         if (next < 0 || next >= V) next = pad;                          // all-NaN logits: nothing compares greater than -inf
         if (!alive) next = pad;
         seq[step + 1] = next;
+        chosen = next;
         if (alive && next == eos) unfinished[b] = 0;
         if (alive && next != eos) atomicOr(any_unfinished + step, 1);      // flag array indexed by step, zeroed by the host wrapper
+    }
+    // the next decode step's input row, LayerNorm(word[next] + type[0]) (what lm_embed_kernel computes), without a launch of its own
+    if (xnext) {
+        __syncthreads();
+        long long t = chosen;
+        t = (t < 0) ? 0 : (t >= V ? V - 1 : t);
+        float ev[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            ev[i] = (c < H) ? word[t * H + c] + type[c] : 0.f;
+            s += ev[i];
+        }
+        const float mean = block_sum256(s, rv) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dd = (tid + 256 * i < H) ? ev[i] - mean : 0.f; q += dd * dd; }
+        const float rstd = 1.0f / sqrtf(block_sum256(q, rv) / (float)H + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if (c < H) xnext[(long long)b * H + c] = (ev[i] - mean) * rstd * eg[c] + eb[c];
+        }
     }
 }
 
@@ -739,9 +767,11 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
     int checked = 0;
     for (int step = 0; step + 1 < max_length; ++step) {
         // token at position `step` -> logits -> token at position step + 1
-        hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, st, lm->dec.word, lm->dec.type, (const float*)nullptr, lm->dec.ln_emb.g, lm->dec.ln_emb.b,
-                           (const int64_t*)(tokens + step), max_length, (const int64_t*)nullptr, (const int64_t*)nullptr, 0, c.eps, H, c.sem_vocab, 1, 1, w.x);
-        LM_HIP(hipGetLastError());
+        if (step == 0) {      // the BOS embedding; every later step's input row is written by the previous step's token-choice kernel
+            hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, st, lm->dec.word, lm->dec.type, (const float*)nullptr, lm->dec.ln_emb.g, lm->dec.ln_emb.b,
+                               (const int64_t*)tokens, max_length, (const int64_t*)nullptr, (const int64_t*)nullptr, 0, c.eps, H, c.sem_vocab, 1, 1, w.x);
+            LM_HIP(hipGetLastError());
+        }
         float *cx = w.x, *cy = w.y;
         for (int i = 0; i < c.dec_layers; ++i) {
             int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, cx, cy, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
@@ -752,13 +782,16 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
         LM_HIP(lm_lin<0>(lm->head_d, cy, H, nullptr, nullptr, c.eps, lg, V, B, st));
         if (V <= 256 * 9)
             hipLaunchKernelGGL(lm_sample_kernel<9>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
-                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf,
+                               lm->dec.word, lm->dec.type, lm->dec.ln_emb.g, lm->dec.ln_emb.b, c.eps, H, w.x);
         else if (V <= 256 * 17)      // (the reference's 4096-entry semantic codebook + 3 special ids)
             hipLaunchKernelGGL(lm_sample_kernel<17>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
-                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf,
+                               lm->dec.word, lm->dec.type, lm->dec.ln_emb.g, lm->dec.ln_emb.b, c.eps, H, w.x);
         else
             hipLaunchKernelGGL(lm_sample_kernel<32>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
-                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf);
+                               do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf,
+                               lm->dec.word, lm->dec.type, lm->dec.ln_emb.g, lm->dec.ln_emb.b, c.eps, H, w.x);
         LM_HIP(hipGetLastError());
         // EOS poll every 8 steps: the loop ends after the step in which the last running sequence emitted EOS
         if ((step & 7) == 7 || step + 2 == max_length) {
