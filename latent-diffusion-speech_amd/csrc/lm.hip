@@ -148,11 +148,16 @@ __global__ void __launch_bounds__(256) lm_embed_kernel(const float* __restrict__
 // ---- Y[n][m] = epi(sum_k X[n][k] * Wt[k][m] + b[m]) for a tile of 8 tokens per workgroup.  A decode step has 1-8 rows, so the
 //      kernel is a latency problem, not a FLOP problem: a workgroup is COLS output columns x KS K-slices (each thread walks K/KS
 //      weights with 16 coalesced loads in flight), the partial sums meet through LDS in a fixed order (slice 0 adds slices 1, 2, ...).
-//      EPI 0: none, 1: GELU, 2: LayerNorm(y + R[n][m]) over m, 3: LayerNorm(GELU(y)); EPI >= 2 needs COLS == M == 256. ----
+//      EPI 0: none, 1: GELU, 2: LayerNorm(y + R[n][m]) over m, 3: LayerNorm(GELU(y)) (EPI 2 / 3 need COLS == M == 256);
+//      4: rotary embedding + cache append of the q | k | v projection (LmRope). ----
+// rotary embedding + cache append of the self-attention q | k | v projection (EPI 4): table row = [sin(d/2) | cos(d/2)], pairs (2p, 2p+1)
+// (modeling_roformer.py:220-245); rotated q goes to Y, rotated k and v to kc / vc [B][heads][cap][d] at slot pos0 + l (row n = b * L + l)
+struct LmRope { const float* table; float* kc; float* vc; int pos0, L, heads, cap; };
+
 template <int EPI, int COLS, int KS>
 __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Wt, const float* __restrict__ bias,
                                                              const float* __restrict__ R, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                                             float* __restrict__ Y, int ldy, int N, int K, int M) {
+                                                             float* __restrict__ Y, int ldy, int N, int K, int M, const LmRope rope) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // xs [K][8] then part [KS-1][COLS][8]
     __shared__ __attribute__((aligned(16))) float red8[16 * 8];
     float* xs = sm;
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __res
     }
     __syncthreads();
     if (ks > 0) {
-        if constexpr (EPI >= 2) {      // the LayerNorm reductions below are workgroup-wide: the other slices take part with zeros
+        if constexpr (EPI == 2 || EPI == 3) {      // the LayerNorm reductions below are workgroup-wide: the other slices take part with zeros
             float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             block_sum8<COLS * KS>(z, red8);      // (returns the totals in z)
 #pragma unroll
@@ -221,7 +226,7 @@ __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __res
         if constexpr (EPI == 1 || EPI == 3) y[j] = gelu_erf(y[j]);
         if constexpr (EPI == 2) { if (ok[j] && R) y[j] += R[(long long)(n0 + j) * M + m]; }
     }
-    if constexpr (EPI >= 2) {      // LayerNorm over each row (COLS == M: slice 0 holds one element of every row per thread); 8 rows at once
+    if constexpr (EPI == 2 || EPI == 3) {      // LayerNorm over each row (COLS == M: slice 0 holds one element of every row per thread); 8 rows at once
         float t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] = ok[j] ? y[j] : 0.f;
@@ -234,33 +239,29 @@ __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = dv[j] * (1.0f / sqrtf(t[j] / (float)M + eps)) * gm + bt;
     }
+    if constexpr (EPI == 4) {
+        // slice 0 is exactly wave 0 (COLS == 64) and M % 64 == 0: the rotation partner of column m sits in the neighbouring lane
+        const int H = M / 3, d = H / rope.heads, hp = d >> 1;
+        const int sec = m / H, c = m - sec * H, hd = c / d, e = c - hd * d;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (ok[j]) Y[(long long)(n0 + j) * ldy + m] = y[j];
-}
-
-// ---- rotary position embedding of q and k (modeling_roformer.py:220-245; table row = [sin(16) | cos(16)] for head dim 32) and
-//      the key/value cache append.  qkv [N][3H] (q | k | v); token n = (b, l) with position pos0 + l; k', v go to
-//      kc / vc [B][heads][cap][d] at slot pos0 + l.  One thread per (token, head, pair). ----
-__global__ void __launch_bounds__(256) lm_rope_kernel(float* __restrict__ qkv, const float* __restrict__ table, int B, int L, int pos0, int H, int heads,
-                                                      float* __restrict__ kc, float* __restrict__ vc, int cap) {
-    const int d = H / heads, hp = d / 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)B * L * heads * hp) return;
-    const int p = (int)(i % hp), hd = (int)((i / hp) % heads);
-    const long long n = i / ((long long)hp * heads);
-    const int l = (int)(n % L), b = (int)(n / L);
-    const float sn = table[(long long)(pos0 + l) * d + p], cs = table[(long long)(pos0 + l) * d + hp + p];
-    float* q = qkv + n * 3 * H + hd * d + 2 * p;
-    float* k = q + H;
-    const float q0 = q[0], q1 = q[1], k0 = k[0], k1 = k[1];
-    q[0] = q0 * cs - q1 * sn; q[1] = q1 * cs + q0 * sn;
-    const float r0 = k0 * cs - k1 * sn, r1 = k1 * cs + k0 * sn;
-    k[0] = r0; k[1] = r1;
-    const long long co = (((long long)b * heads + hd) * cap + pos0 + l) * d + 2 * p;
-    kc[co] = r0; kc[co + 1] = r1;
-    const float* v = k + H;
-    vc[co] = v[0]; vc[co + 1] = v[1];
+        for (int j = 0; j < 8; ++j) {
+            const int n = (n0 + j < N) ? n0 + j : n0;
+            const int b = n / rope.L, pos = rope.pos0 + (n - b * rope.L);
+            const float sn = rope.table[(long long)pos * d + (e >> 1)], cs = rope.table[(long long)pos * d + hp + (e >> 1)];
+            const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[j]), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+            const float rot = (e & 1) ? y[j] * cs + other * sn : y[j] * cs - other * sn;
+            const long long co = (((long long)b * rope.heads + hd) * rope.cap + pos) * d + e;
+            if (ok[j]) {
+                if (sec == 0) Y[(long long)n * ldy + m] = rot;
+                else if (sec == 1) rope.kc[co] = rot;
+                else rope.vc[co] = y[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ok[j]) Y[(long long)(n0 + j) * ldy + m] = y[j];
+    }
 }
 
 // cross-attention keys / values of the encoder states into the cache layout: kv [N][2H] (k | v) -> kc / vc [B][heads][cap][d]
@@ -650,14 +651,18 @@ void lm_plan(const lds_lm* lm, LmArena& A, int B, int L, int cap, LmWs& w) {
     }
 }
 template <int EPI>
-hipError_t lm_lin(const LmLinear& W, const float* X, int ldx, const float* R, const LmLN* ln, float eps, float* Y, int ldy, int N, hipStream_t st) {
-    constexpr int COLS = (EPI >= 2) ? 256 : 64, KS = (EPI >= 2) ? 4 : 16;      // 1024 threads either way
+hipError_t lm_lin(const LmLinear& W, const float* X, int ldx, const float* R, const LmLN* ln, float eps, float* Y, int ldy, int N, hipStream_t st,
+                  const LmRope* rope = nullptr) {
+    constexpr bool ROWS = EPI == 2 || EPI == 3;                                 // complete rows per workgroup (LayerNorm epilogues)
+    constexpr int COLS = ROWS ? 256 : 64, KS = ROWS ? 4 : 16;                   // 1024 threads either way
     if (W.K % (16 * KS)) return hipErrorInvalidValue;
-    if (EPI >= 2 && W.M != 256) return hipErrorInvalidValue;
+    if (ROWS && W.M != 256) return hipErrorInvalidValue;
+    if (EPI == 4 && (!rope || W.M % 192 || (W.M / 3 / rope->heads) % 2)) return hipErrorInvalidValue;
+    const LmRope ro = rope ? *rope : LmRope{nullptr, nullptr, nullptr, 0, 1, 1, 0};
     const dim3 grid((W.M + COLS - 1) / COLS, (N + 7) / 8);
     const size_t lds = ((size_t)W.K * 8 + (size_t)(KS - 1) * COLS * 8) * sizeof(float);
     hipLaunchKernelGGL((lm_linear_kernel<EPI, COLS, KS>), grid, dim3(COLS * KS), lds, st, X, ldx, W.wt, W.b, R, ln ? ln->g : nullptr, ln ? ln->b : nullptr, eps, Y,
-                       ldy, N, W.K, W.M);
+                       ldy, N, W.K, W.M, ro);
     return hipGetLastError();
 }
 hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* vc, int cap, int B, int Lq, int Lk, const lds_lm_cfg& c, float* out, hipStream_t st) {
@@ -671,11 +676,9 @@ int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& 
              const float* ckc, const float* cvc, int Lenc, hipStream_t st) {
     const lds_lm_cfg& c = lm->cfg;
     const int H = c.hidden, N = B * L;
-    LM_HIP(lm_lin<0>(Ly.self.qkv, x, H, nullptr, nullptr, c.eps, w.qkv, 3 * H, N, st));
     {
-        const long long work = (long long)N * c.heads * (H / c.heads / 2);
-        hipLaunchKernelGGL(lm_rope_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, w.qkv, s.table, B, L, pos0, H, c.heads, kc, vc, cap);
-        LM_HIP(hipGetLastError());
+        const LmRope rope{s.table, kc, vc, pos0, L, c.heads, cap};      // rotary embedding and cache append in the projection's epilogue
+        LM_HIP(lm_lin<4>(Ly.self.qkv, x, H, nullptr, nullptr, c.eps, w.qkv, 3 * H, N, st, &rope));
     }
     LM_HIP(lm_attention(w.qkv, 3 * H, kc, vc, cap, B, L, pos0 + L, c, w.ctx, st));
     LM_HIP(lm_lin<2>(Ly.self.o, w.ctx, H, x, &Ly.self.ln, c.eps, y, H, N, st));
