@@ -264,6 +264,153 @@ __global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __res
     }
 }
 
+// ---- Deferred LayerNorm.  A linear whose epilogue normalises complete rows needs one workgroup per row tile, i.e. ONE CU streaming the
+//      whole weight matrix (~55 GB/s: 11 us for 256 x 256, four of them per decode step).  Here the producing linear keeps its
+//      M / 64 column workgroups (5 us) and stores the PRE-normalisation rows; whoever reads them next normalises on the way in:
+//        * a consumer linear stages its 8 input rows in LDS anyway -- it computes their mean / variance there (xg, xb != null);
+//        * a consumer that adds them as the residual stages those rows as well (rg, rb != null).
+//      The statistics are recomputed by every consuming workgroup (8 x 256 values: two block reductions), in a fixed order.
+//      EPI 0: none, 1: GELU, 4: rotary + cache append (LmRope), 5: y + residual. ----
+template <int NT>
+static __device__ __forceinline__ void lm_rows_ln_inplace(float* buf, int L, const float* __restrict__ g, const float* __restrict__ bta, float eps, float* red8) {
+    // wave j (< 8) owns row j: two wave reductions, no workgroup-wide reduction; the (mean, rstd) pairs are published through LDS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave < 8) {
+        float sum = 0.f;
+        for (int k = lane; k < L; k += 64) sum += buf[8 * k + wave];
+        const float mean = wave_sum(sum) / (float)L;
+        float q = 0.f;
+        for (int k = lane; k < L; k += 64) { const float d = buf[8 * k + wave] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)L + eps);
+        if (lane == 0) { red8[2 * wave] = mean; red8[2 * wave + 1] = rstd; }
+    }
+    __syncthreads();
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mean[j] = red8[2 * j]; rstd[j] = red8[2 * j + 1]; }
+    for (int k = tid; k < L; k += NT) {
+        const float gk = g[k], bk = bta[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) buf[8 * k + j] = (buf[8 * k + j] - mean[j]) * rstd[j] * gk + bk;
+    }
+    __syncthreads();
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(1024) lm_linear_dln_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ xg, const float* __restrict__ xb,
+                                                            const float* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ R,
+                                                            const float* __restrict__ rg, const float* __restrict__ rb, float eps, float* __restrict__ Y, int ldy,
+                                                            int N, int K, int M, const LmRope rope) {
+    constexpr int COLS = 64, KS = 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // xs [K][8], part [KS-1][COLS][8], rs [M][8] (residual rows), red8 [16][8]
+    float* xs = sm;
+    float* part = sm + (size_t)K * 8;
+    float* rs = part + (size_t)(KS - 1) * COLS * 8;
+    float* red8 = rs + (size_t)((EPI == 5) ? M : 0) * 8;
+    const int tid = threadIdx.x, col = tid % COLS, ks = tid / COLS;
+    const int m = blockIdx.x * COLS + col, n0 = blockIdx.y * 8;
+    for (int i = tid; i < K * 8; i += 1024) {
+        const int k = i >> 3, j = i & 7;
+        xs[i] = (n0 + j < N) ? X[(long long)(n0 + j) * ldx + k] : 0.f;
+    }
+    if constexpr (EPI == 5) {
+        for (int i = tid; i < M * 8; i += 1024) {
+            const int k = i >> 3, j = i & 7;
+            rs[i] = (n0 + j < N) ? R[(long long)(n0 + j) * M + k] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (xg) lm_rows_ln_inplace<1024>(xs, K, xg, xb, eps, red8);
+    if constexpr (EPI == 5) {
+        if (rg) lm_rows_ln_inplace<1024>(rs, M, rg, rb, eps, red8);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int kq = K / KS, k0 = ks * kq;                            // K % 256 == 0 (checked by the launcher)
+    if (m < M) {
+        const float* wp = Wt + (long long)k0 * M + m;
+        for (int kk = 0; kk < kq; kk += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wp[(long long)(kk + u) * M];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xs + 8 * (k0 + kk + u)), b = *reinterpret_cast<const f32x4*>(xs + 8 * (k0 + kk + u) + 4);
+                acc[0] = fmaf(w[u], a[0], acc[0]); acc[1] = fmaf(w[u], a[1], acc[1]); acc[2] = fmaf(w[u], a[2], acc[2]); acc[3] = fmaf(w[u], a[3], acc[3]);
+                acc[4] = fmaf(w[u], b[0], acc[4]); acc[5] = fmaf(w[u], b[1], acc[5]); acc[6] = fmaf(w[u], b[2], acc[6]); acc[7] = fmaf(w[u], b[3], acc[7]);
+            }
+        }
+    }
+    if (ks > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[((ks - 1) * COLS + col) * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll 1
+    for (int q0 = 0; q0 < KS - 1; q0 += 5) {      // five slices in flight at a time (register budget of a 1024-thread workgroup)
+        float t[5][8];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[q][j] = part[((q0 + q) * COLS + col) * 8 + j];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += t[q][j];
+    }
+    const float bm = (m < M && bias) ? bias[m] : 0.f;
+    float y[8];
+    bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        y[j] = acc[j] + bm;
+        ok[j] = m < M && n0 + j < N;
+        if constexpr (EPI == 1) y[j] = gelu_erf(y[j]);
+        if constexpr (EPI == 5) { if (m < M) y[j] += rs[8 * m + j]; }
+    }
+    if constexpr (EPI == 4) {
+        // slice 0 is exactly wave 0 and M % 64 == 0: the rotation partner of column m sits in the neighbouring lane
+        const int H = M / 3, d = H / rope.heads, hp = d >> 1;
+        const int sec = m / H, c = m - sec * H, hd = c / d, e = c - hd * d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = (n0 + j < N) ? n0 + j : n0;
+            const int b = n / rope.L, pos = rope.pos0 + (n - b * rope.L);
+            const float sn = rope.table[(long long)pos * d + (e >> 1)], cs = rope.table[(long long)pos * d + hp + (e >> 1)];
+            const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[j]), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+            const float rot = (e & 1) ? y[j] * cs + other * sn : y[j] * cs - other * sn;
+            const long long co = (((long long)b * rope.heads + hd) * rope.cap + pos) * d + e;
+            if (ok[j]) {
+                if (sec == 0) Y[(long long)n * ldy + m] = rot;
+                else if (sec == 1) rope.kc[co] = rot;
+                else rope.vc[co] = y[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ok[j]) Y[(long long)(n0 + j) * ldy + m] = y[j];
+    }
+}
+
+// LayerNorm of rows [N][H] (the encoder's final states, which leave the library normalised): one workgroup per row, H <= 1024
+__global__ void __launch_bounds__(256) lm_ln_rows_kernel(const float* __restrict__ in, const float* __restrict__ g, const float* __restrict__ bta, float eps, int H,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4];
+    const long long n = blockIdx.x;
+    const int tid = threadIdx.x;
+    float v[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; v[i] = (c < H) ? in[n * H + c] : 0.f; s += v[i]; }
+    const float mean = block_sum256(s, red) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float d = (tid + 256 * i < H) ? v[i] - mean : 0.f; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum256(q, red) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; if (c < H) out[n * H + c] = (v[i] - mean) * rstd * g[c] + bta[c]; }
+}
+
 // cross-attention keys / values of the encoder states into the cache layout: kv [N][2H] (k | v) -> kc / vc [B][heads][cap][d]
 __global__ void __launch_bounds__(256) lm_kv_pack_kernel(const float* __restrict__ kv, int B, int L, int H, int heads, float* __restrict__ kc,
                                                          float* __restrict__ vc, int cap) {
@@ -635,12 +782,12 @@ struct LmArena {
         return (float*)p;
     }
 };
-struct LmWs { float *x, *y, *qkv, *ctx, *ff, *kv, *logits, *kc_tmp, *vc_tmp; int* flags; std::vector<float*> kc, vc, ckc, cvc; };
+struct LmWs { float *x, *y, *z, *qkv, *ctx, *ff, *kv, *logits, *kc_tmp, *vc_tmp; int* flags; std::vector<float*> kc, vc, ckc, cvc; };
 // N = rows processed at once (B * L for the prefill, B for a decode step)
 void lm_plan(const lds_lm* lm, LmArena& A, int B, int L, int cap, LmWs& w) {
     const lds_lm_cfg& c = lm->cfg;
     const size_t N = (size_t)B * (L > 1 ? L : 1), H = c.hidden;
-    w.x = A.f(N * H); w.y = A.f(N * H); w.qkv = A.f(N * 3 * H); w.ctx = A.f(N * H); w.ff = A.f(N * c.inter); w.kv = A.f(N * 2 * H);
+    w.x = A.f(N * H); w.y = A.f(N * H); w.z = A.f(N * H); w.qkv = A.f(N * 3 * H); w.ctx = A.f(N * H); w.ff = A.f(N * c.inter); w.kv = A.f(N * 2 * H);
     w.logits = A.f((size_t)B * c.sem_vocab);
     w.kc_tmp = A.f(N * H); w.vc_tmp = A.f(N * H);
     w.flags = (int*)A.f((size_t)cap + B + 64);
@@ -671,28 +818,54 @@ hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* v
     hipLaunchKernelGGL(lm_attn_kernel, dim3(total), dim3(256), lds, st, q, ldq, kc, vc, cap, Lq, Lk, c.hidden, c.heads, out);
     return hipGetLastError();
 }
-// one BERT-style post-LN layer over N = B * L rows; self-attention over [pos0, pos0 + L) appended to the cache (kc, vc)
-int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& w, float*& x, float*& y, int B, int L, int pos0, float* kc, float* vc, int cap,
+// rows [N][hidden] together with the LayerNorm that is still owed to them (ln == nullptr: already normalised)
+struct LmRows { float* p; const LmLN* ln; };
+
+template <int EPI>
+hipError_t lm_dln(const LmLinear& W, const LmRows& X, int ldx, const LmRows* R, float eps, float* Y, int ldy, int N, hipStream_t st, const LmRope* rope = nullptr) {
+    if (W.K % 256 || ((EPI == 4 || EPI == 5) && W.M % 64)) return hipErrorInvalidValue;
+    if (EPI == 5 && !R) return hipErrorInvalidValue;
+    if (EPI == 4 && (!rope || W.M % 192 || (W.M / 3 / rope->heads) % 2)) return hipErrorInvalidValue;
+    auto kern = lm_linear_dln_kernel<EPI>;
+    static std::atomic<unsigned long long> attr_done{0};
+    hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
+    if (e != hipSuccess) return e;
+    const size_t lds = ((size_t)W.K * 8 + (size_t)15 * 64 * 8 + (EPI == 5 ? (size_t)W.M * 8 : 0) + 16 * 8) * sizeof(float);
+    const LmRope ro = rope ? *rope : LmRope{nullptr, nullptr, nullptr, 0, 1, 1, 0};
+    hipLaunchKernelGGL(kern, dim3((W.M + 63) / 64, (N + 7) / 8), dim3(1024), lds, st, (const float*)X.p, ldx, X.ln ? X.ln->g : nullptr, X.ln ? X.ln->b : nullptr, W.wt, W.b,
+                       R ? (const float*)R->p : nullptr, (R && R->ln) ? R->ln->g : nullptr, (R && R->ln) ? R->ln->b : nullptr, eps, Y, ldy, N, W.K, W.M, ro);
+    return hipGetLastError();
+}
+
+// one BERT-style post-LN layer over N = B * L rows; self-attention over [pos0, pos0 + L) appended to the cache (kc, vc).
+// Every LayerNorm is deferred to the readers of its rows (lm_linear_dln_kernel): `x` comes in, and goes out, as rows + owed LayerNorm.
+// The three row buffers of the workspace rotate: input -> a (attention block) -> c (cross-attention block) -> output in the input's buffer.
+int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& w, LmRows& x, int B, int L, int pos0, float* kc, float* vc, int cap,
              const float* ckc, const float* cvc, int Lenc, hipStream_t st) {
     const lds_lm_cfg& c = lm->cfg;
     const int H = c.hidden, N = B * L;
+    if (Ly.self.o.M != H || Ly.ff2.M != H || (Ly.has_cross && (Ly.cross.o.M != H || Ly.cross.q.K != H))) return lm_fail(LDS_EINVAL, "layer shapes");
+    float* free1 = (x.p == w.x) ? w.y : w.x;
+    float* free2 = (x.p == w.z) ? w.y : w.z;
+    if (free1 == free2) free2 = w.x;
     {
         const LmRope rope{s.table, kc, vc, pos0, L, c.heads, cap};      // rotary embedding and cache append in the projection's epilogue
-        LM_HIP(lm_lin<4>(Ly.self.qkv, x, H, nullptr, nullptr, c.eps, w.qkv, 3 * H, N, st, &rope));
+        LM_HIP(lm_dln<4>(Ly.self.qkv, x, H, nullptr, c.eps, w.qkv, 3 * H, N, st, &rope));
     }
     LM_HIP(lm_attention(w.qkv, 3 * H, kc, vc, cap, B, L, pos0 + L, c, w.ctx, st));
-    LM_HIP(lm_lin<2>(Ly.self.o, w.ctx, H, x, &Ly.self.ln, c.eps, y, H, N, st));
-    float* cur = y;
-    float* oth = x;
+    const LmRows ctx{w.ctx, nullptr};
+    LM_HIP(lm_dln<5>(Ly.self.o, ctx, H, &x, c.eps, free1, H, N, st));               // a = W_o ctx + LN(x)
+    LmRows cur{free1, &Ly.self.ln};
     if (Ly.has_cross) {
-        LM_HIP(lm_lin<0>(Ly.cross.q, cur, H, nullptr, nullptr, c.eps, w.qkv, H, N, st));
+        LM_HIP(lm_dln<0>(Ly.cross.q, cur, H, nullptr, c.eps, w.qkv, H, N, st));
         LM_HIP(lm_attention(w.qkv, H, ckc, cvc, Lenc, B, L, Lenc, c, w.ctx, st));
-        LM_HIP(lm_lin<2>(Ly.cross.o, w.ctx, H, cur, &Ly.cross.ln, c.eps, oth, H, N, st));
-        float* t = cur; cur = oth; oth = t;
+        LM_HIP(lm_dln<5>(Ly.cross.o, ctx, H, &cur, c.eps, free2, H, N, st));        // c = W_o' ctx' + LN(a)
+        cur = LmRows{free2, &Ly.cross.ln};
     }
-    LM_HIP(lm_lin<1>(Ly.ff1, cur, H, nullptr, nullptr, c.eps, w.ff, c.inter, N, st));
-    LM_HIP(lm_lin<2>(Ly.ff2, w.ff, c.inter, cur, &Ly.ln_ff, c.eps, oth, H, N, st));
-    if (oth != x) { float* t = x; x = y; y = t; }      // the result is in `x` on return (the two buffers swap roles)
+    LM_HIP(lm_dln<1>(Ly.ff1, cur, H, nullptr, c.eps, w.ff, c.inter, N, st));
+    const LmRows ff{w.ff, nullptr};
+    LM_HIP(lm_dln<5>(Ly.ff2, ff, c.inter, &cur, c.eps, x.p, H, N, st));              // g = W_2 f + LN(cur), into the input's buffer (no longer read)
+    x.ln = &Ly.ln_ff;
     return LDS_OK;
 }
 }  // namespace
@@ -721,13 +894,18 @@ extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* to
     hipLaunchKernelGGL(lm_embed_kernel, dim3(N), dim3(256), 0, st, lm->enc.word, lm->enc.type, lm->spk, lm->enc.ln_emb.g, lm->enc.ln_emb.b, phone, 1, tone,
                        lm->spk ? spk_id : nullptr, 1, c.eps, H, c.text_vocab, c.type_vocab, c.n_spk_rows > 0 ? c.n_spk_rows : 1, w.x);
     LM_HIP(hipGetLastError());
-    float *cx = w.x, *cy = w.y;
+    LmRows cx{w.x, nullptr};
     for (const LmLayer& Ly : lm->enc.layers) {
         // the encoder's "cache" is just this layer's keys / values for all L positions
-        int r = lm_layer(lm, lm->enc, Ly, w, cx, cy, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, st);
+        int r = lm_layer(lm, lm->enc, Ly, w, cx, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, st);
         if (r != LDS_OK) return r;
     }
-    LM_HIP(hipMemcpyAsync(enc, cx, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));
+    if (cx.ln) {      // the states leave the library normalised
+        hipLaunchKernelGGL(lm_ln_rows_kernel, dim3(N), dim3(256), 0, st, (const float*)cx.p, cx.ln->g, cx.ln->b, c.eps, H, enc);
+        LM_HIP(hipGetLastError());
+    } else {
+        LM_HIP(hipMemcpyAsync(enc, cx.p, sizeof(float) * N * H, hipMemcpyDeviceToDevice, st));
+    }
     return LDS_OK;
 }
 
@@ -775,14 +953,16 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
                                (const int64_t*)tokens, max_length, (const int64_t*)nullptr, (const int64_t*)nullptr, 0, c.eps, H, c.sem_vocab, 1, 1, w.x);
             LM_HIP(hipGetLastError());
         }
-        float *cx = w.x, *cy = w.y;
+        LmRows cx{w.x, nullptr};
         for (int i = 0; i < c.dec_layers; ++i) {
-            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, cx, cy, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
+            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, cx, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
             if (r != LDS_OK) return r;
         }
-        LM_HIP(lm_lin<3>(lm->head_t, cx, H, nullptr, &lm->head_ln, c.eps, cy, H, B, st));
+        // LM head: h = GELU(W_t LN(x)) stored un-normalised, logits = W_d LN(h)
+        LM_HIP(lm_dln<1>(lm->head_t, cx, H, nullptr, c.eps, w.ctx, H, B, st));
+        const LmRows hrows{w.ctx, &lm->head_ln};
         float* lg = logits_out ? logits_out + (size_t)step * B * V : w.logits;
-        LM_HIP(lm_lin<0>(lm->head_d, cy, H, nullptr, nullptr, c.eps, lg, V, B, st));
+        LM_HIP(lm_dln<0>(lm->head_d, hrows, H, nullptr, c.eps, lg, V, B, st));
         if (V <= 256 * 9)
             hipLaunchKernelGGL(lm_sample_kernel<9>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
                                do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf,
