@@ -68,28 +68,6 @@ static __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < NT / 64; ++i) t += red[i];
     return t;
 }
-// eight sums at once (the rows of a token tile): one barrier pair for all of them
-template <int NT>
-static __device__ __forceinline__ void block_sum8(float (&v)[8], float* red8) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = wave_sum(v[j]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red8[(threadIdx.x >> 6) * 8 + j] = v[j];
-    }
-    __syncthreads();
-    // (two 16-byte reads per wave slot, four slots in flight: fully unrolled scalar reads keep 128 values live and spill)
-    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int i = 0; i < NT / 64; ++i) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(red8 + i * 8), b = *reinterpret_cast<const f32x4*>(red8 + i * 8 + 4);
-        t[0] += a[0]; t[1] += a[1]; t[2] += a[2]; t[3] += a[3];
-        t[4] += b[0]; t[5] += b[1]; t[6] += b[2]; t[7] += b[3];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = t[j];
-}
 static __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
@@ -145,124 +123,12 @@ __global__ void __launch_bounds__(256) lm_embed_kernel(const float* __restrict__
         if (tid + 256 * i < H) out[(long long)n * H + tid + 256 * i] = v[i];
 }
 
-// ---- Y[n][m] = epi(sum_k X[n][k] * Wt[k][m] + b[m]) for a tile of 8 tokens per workgroup.  A decode step has 1-8 rows, so the
-//      kernel is a latency problem, not a FLOP problem: a workgroup is COLS output columns x KS K-slices (each thread walks K/KS
-//      weights with 16 coalesced loads in flight), the partial sums meet through LDS in a fixed order (slice 0 adds slices 1, 2, ...).
-//      EPI 0: none, 1: GELU, 2: LayerNorm(y + R[n][m]) over m, 3: LayerNorm(GELU(y)) (EPI 2 / 3 need COLS == M == 256);
-//      4: rotary embedding + cache append of the q | k | v projection (LmRope). ----
+// ---- Y[n][m] = epi(sum_k LNopt(X)[n][k] * Wt[k][m] + b[m]) for a tile of 8 tokens per workgroup.  A decode step has 1-8 rows, so the
+//      kernels are a latency problem, not a FLOP problem: a workgroup is 64 output columns x 16 K-slices (each thread walks K/16 weights
+//      with 16 coalesced loads in flight), the partial sums meet through LDS in a fixed order (slice 0 adds slices 1, 2, ...). ----
 // rotary embedding + cache append of the self-attention q | k | v projection (EPI 4): table row = [sin(d/2) | cos(d/2)], pairs (2p, 2p+1)
 // (modeling_roformer.py:220-245); rotated q goes to Y, rotated k and v to kc / vc [B][heads][cap][d] at slot pos0 + l (row n = b * L + l)
 struct LmRope { const float* table; float* kc; float* vc; int pos0, L, heads, cap; };
-
-template <int EPI, int COLS, int KS>
-__global__ void __launch_bounds__(COLS * KS) lm_linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                             const float* __restrict__ R, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                                             float* __restrict__ Y, int ldy, int N, int K, int M, const LmRope rope) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // xs [K][8] then part [KS-1][COLS][8]
-    __shared__ __attribute__((aligned(16))) float red8[16 * 8];
-    float* xs = sm;
-    float* part = sm + (size_t)K * 8;
-    const int tid = threadIdx.x, col = tid % COLS, ks = tid / COLS;
-    const int m = blockIdx.x * COLS + col, n0 = blockIdx.y * 8;
-    for (int i = tid; i < K * 8; i += COLS * KS) {
-        const int k = i >> 3, j = i & 7;
-        xs[i] = (n0 + j < N) ? X[(long long)(n0 + j) * ldx + k] : 0.f;
-    }
-    __syncthreads();
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int kq = K / KS, k0 = ks * kq;                            // K % (16 * KS) == 0 (checked by the launcher)
-    if (m < M) {
-        const float* wp = Wt + (long long)k0 * M + m;
-        for (int kk = 0; kk < kq; kk += 16) {
-            float w[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = wp[(long long)(kk + u) * M];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(xs + 8 * (k0 + kk + u)), b = *reinterpret_cast<const f32x4*>(xs + 8 * (k0 + kk + u) + 4);
-                acc[0] = fmaf(w[u], a[0], acc[0]); acc[1] = fmaf(w[u], a[1], acc[1]); acc[2] = fmaf(w[u], a[2], acc[2]); acc[3] = fmaf(w[u], a[3], acc[3]);
-                acc[4] = fmaf(w[u], b[0], acc[4]); acc[5] = fmaf(w[u], b[1], acc[5]); acc[6] = fmaf(w[u], b[2], acc[6]); acc[7] = fmaf(w[u], b[3], acc[7]);
-            }
-        }
-    }
-    if (ks > 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) part[((ks - 1) * COLS + col) * 8 + j] = acc[j];
-    }
-    __syncthreads();
-    if (ks > 0) {
-        if constexpr (EPI == 2 || EPI == 3) {      // the LayerNorm reductions below are workgroup-wide: the other slices take part with zeros
-            float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            block_sum8<COLS * KS>(z, red8);      // (returns the totals in z)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = 0.f;
-            block_sum8<COLS * KS>(z, red8);
-        }
-        return;
-    }
-    // five slices (40 partials) in flight at a time: all 120 at once do not fit beside the rest in the 128 registers of a 1024-thread
-    // workgroup and spill
-    constexpr int QC = (KS - 1) % 5 == 0 ? 5 : 3;
-    static_assert((KS - 1) % QC == 0, "K slices per workgroup: 4 or 16");
-#pragma unroll 1
-    for (int q0 = 0; q0 < KS - 1; q0 += QC) {
-        float t[QC][8];
-#pragma unroll
-        for (int q = 0; q < QC; ++q)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[q][j] = part[((q0 + q) * COLS + col) * 8 + j];
-#pragma unroll
-        for (int q = 0; q < QC; ++q)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += t[q][j];
-    }
-    const float bm = (m < M && bias) ? bias[m] : 0.f;
-    float y[8];
-    bool ok[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        y[j] = acc[j] + bm;
-        ok[j] = m < M && n0 + j < N;
-        if constexpr (EPI == 1 || EPI == 3) y[j] = gelu_erf(y[j]);
-        if constexpr (EPI == 2) { if (ok[j] && R) y[j] += R[(long long)(n0 + j) * M + m]; }
-    }
-    if constexpr (EPI == 2 || EPI == 3) {      // LayerNorm over each row (COLS == M: slice 0 holds one element of every row per thread); 8 rows at once
-        float t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = ok[j] ? y[j] : 0.f;
-        block_sum8<COLS * KS>(t, red8);
-        float dv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { dv[j] = ok[j] ? y[j] - t[j] / (float)M : 0.f; t[j] = dv[j] * dv[j]; }
-        block_sum8<COLS * KS>(t, red8);
-        const float gm = (m < M) ? g[m] : 0.f, bt = (m < M) ? bta[m] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = dv[j] * (1.0f / sqrtf(t[j] / (float)M + eps)) * gm + bt;
-    }
-    if constexpr (EPI == 4) {
-        // slice 0 is exactly wave 0 (COLS == 64) and M % 64 == 0: the rotation partner of column m sits in the neighbouring lane
-        const int H = M / 3, d = H / rope.heads, hp = d >> 1;
-        const int sec = m / H, c = m - sec * H, hd = c / d, e = c - hd * d;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = (n0 + j < N) ? n0 + j : n0;
-            const int b = n / rope.L, pos = rope.pos0 + (n - b * rope.L);
-            const float sn = rope.table[(long long)pos * d + (e >> 1)], cs = rope.table[(long long)pos * d + hp + (e >> 1)];
-            const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[j]), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-            const float rot = (e & 1) ? y[j] * cs + other * sn : y[j] * cs - other * sn;
-            const long long co = (((long long)b * rope.heads + hd) * rope.cap + pos) * d + e;
-            if (ok[j]) {
-                if (sec == 0) Y[(long long)n * ldy + m] = rot;
-                else if (sec == 1) rope.kc[co] = rot;
-                else rope.vc[co] = y[j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ok[j]) Y[(long long)(n0 + j) * ldy + m] = y[j];
-    }
-}
 
 // ---- Deferred LayerNorm.  A linear whose epilogue normalises complete rows needs one workgroup per row tile, i.e. ONE CU streaming the
 //      whole weight matrix (~55 GB/s: 11 us for 256 x 256, four of them per decode step).  Here the producing linear keeps its
@@ -797,21 +663,6 @@ void lm_plan(const lds_lm* lm, LmArena& A, int B, int L, int cap, LmWs& w) {
         w.ckc.push_back(A.f((size_t)B * H * L)); w.cvc.push_back(A.f((size_t)B * H * L));
     }
 }
-template <int EPI>
-hipError_t lm_lin(const LmLinear& W, const float* X, int ldx, const float* R, const LmLN* ln, float eps, float* Y, int ldy, int N, hipStream_t st,
-                  const LmRope* rope = nullptr) {
-    constexpr bool ROWS = EPI == 2 || EPI == 3;                                 // complete rows per workgroup (LayerNorm epilogues)
-    constexpr int COLS = ROWS ? 256 : 64, KS = ROWS ? 4 : 16;                   // 1024 threads either way
-    if (W.K % (16 * KS)) return hipErrorInvalidValue;
-    if (ROWS && W.M != 256) return hipErrorInvalidValue;
-    if (EPI == 4 && (!rope || W.M % 192 || (W.M / 3 / rope->heads) % 2)) return hipErrorInvalidValue;
-    const LmRope ro = rope ? *rope : LmRope{nullptr, nullptr, nullptr, 0, 1, 1, 0};
-    const dim3 grid((W.M + COLS - 1) / COLS, (N + 7) / 8);
-    const size_t lds = ((size_t)W.K * 8 + (size_t)(KS - 1) * COLS * 8) * sizeof(float);
-    hipLaunchKernelGGL((lm_linear_kernel<EPI, COLS, KS>), grid, dim3(COLS * KS), lds, st, X, ldx, W.wt, W.b, R, ln ? ln->g : nullptr, ln ? ln->b : nullptr, eps, Y,
-                       ldy, N, W.K, W.M, ro);
-    return hipGetLastError();
-}
 hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* vc, int cap, int B, int Lq, int Lk, const lds_lm_cfg& c, float* out, hipStream_t st) {
     const int total = B * Lq * c.heads;
     const size_t lds = (size_t)(((Lk + 63) & ~63) + 4 * 34) * sizeof(float);
@@ -929,7 +780,10 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
     int* any_unf = w.flags + B;                // [max_length]: 1 when a sequence is still running after step s
     // cross-attention keys / values of every decoder layer, once
     for (int i = 0; i < c.dec_layers; ++i) {
-        LM_HIP(lm_lin<0>(lm->dec.layers[i].cross.kv, enc, H, nullptr, nullptr, c.eps, w.kv, 2 * H, B * L, st));
+        {
+            const LmRows er{const_cast<float*>(enc), nullptr};
+            LM_HIP(lm_dln<0>(lm->dec.layers[i].cross.kv, er, H, nullptr, c.eps, w.kv, 2 * H, B * L, st));
+        }
         hipLaunchKernelGGL(lm_kv_pack_kernel, dim3((unsigned)(((long long)B * L * H + 255) / 256)), dim3(256), 0, st, w.kv, B, L, H, c.heads, w.ckc[i], w.cvc[i], L);
         LM_HIP(hipGetLastError());
     }
