@@ -612,8 +612,8 @@ bool lm_stack(lds_lm* lm, LmTensors& T, const std::string& p, int vocab, int typ
 extern "C" int lds_lm_create(const lds_lm_cfg* cfg, int n, const char* const* names, const float* const* ptrs, const int64_t* numel, lds_lm** out) {
     if (!cfg || !names || !ptrs || !numel || !out) return lm_fail(LDS_EINVAL, "null argument");
     if (cfg->hidden != 256 || cfg->heads <= 0 || cfg->hidden % cfg->heads || cfg->hidden / cfg->heads > 32 || (cfg->hidden / cfg->heads) % 2 ||
-        cfg->sem_vocab > 256 * 32 || cfg->inter > 4096)
-        return lm_fail(LDS_EINVAL, "unsupported LM shape (hidden must be 256, head dim even and <= 32, vocabulary <= 8192)");
+        cfg->sem_vocab > 256 * 32 || cfg->inter <= 0 || cfg->inter % 256 || cfg->inter > 3840)      // (inter: the staged rows of ff2 must fit in LDS)
+        return lm_fail(LDS_EINVAL, "unsupported LM shape (hidden must be 256, head dim even and <= 32, vocabulary <= 8192, intermediate size a multiple of 256 <= 3840)");
     LmTensors T;
     for (int i = 0; i < n; ++i) T.m[names[i]] = {ptrs[i], numel[i]};
     lds_lm* lm = new lds_lm();
