@@ -117,7 +117,7 @@ struct DmaKernel {
 
     __device__ __forceinline__ DmaKernel(const DmaConvArgs& p_, float* s_) : p(p_), smem(s_) {}
 
-    __device__ __forceinline__ void setup() {
+    __device__ __forceinline__ void setup_keep_acc() {      // everything but the accumulators (second phase of conv_dma_pair_kernel)
         const int tid = threadIdx.x;
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,6 +161,9 @@ struct DmaKernel {
         arow = wm * TM * 32 + c;
 #pragma unroll
         for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
+    }
+    __device__ __forceinline__ void setup() {
+        setup_keep_acc();
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -650,6 +653,43 @@ __global__ void __launch_bounds__(256, ((VOC && KT == 2) ? 2 : DmaCfg<BM, BN, KT
     k.epilogue();
 }
 
+// Two reductions into one set of accumulators: the k 3 convolution of a resnet's second half, then its 1x1 shortcut over the block
+// input (two K4P sources), then ONE epilogue (launch_conv_dma_pair).  The second phase starts its own DMA ring after the first has
+// drained (one exposed first-tile latency, ~2 us, against a launch, ~8 us, and the shortcut tensor's round trip through memory).
+struct DmaPairArgs { DmaConvArgs a3, a1; };
+
+template <int BM, int BN, int BK3, int BK1, int NST>
+struct PairCfg {
+    using C3 = DmaCfg<BM, BN, 3, 1, false, BK3, NST, 1>;
+    using C1 = DmaCfg<BM, BN, 1, 1, false, BK1, NST, 1>;
+    static constexpr size_t LDS_BYTES = C3::LDS_BYTES > C1::LDS_BYTES ? C3::LDS_BYTES : C1::LDS_BYTES;
+    static constexpr int OCC = C3::OCC < C1::OCC ? C3::OCC : C1::OCC;
+    static_assert(C3::NACC == C1::NACC && C3::TM == C1::TM && C3::TN == C1::TN && C3::SPLIT == C1::SPLIT, "the phases share the accumulators");
+};
+
+template <int BM, int BN, int BK3, int BK1, int NST>
+__global__ void __launch_bounds__(256, (PairCfg<BM, BN, BK3, BK1, NST>::OCC)) conv_dma_pair_kernel(const DmaPairArgs pp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using K3 = DmaKernel<BM, BN, 3, 1, false, BK3, NST, 1, false>;
+    using K1 = DmaKernel<BM, BN, 1, 1, false, BK1, NST, 1, false>;
+    K1 k1(pp.a1, smem);
+    {
+        K3 k3(pp.a3, smem);
+        k3.setup();
+        k3.mainloop();
+#pragma unroll
+        for (int a = 0; a < K3::NACC; ++a)
+#pragma unroll
+            for (int i = 0; i < K3::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < K3::TN; ++j) k1.acc[a][i][j] = k3.acc[a][i][j];
+    }
+    __syncthreads();                // every wave is done reading the first phase's stages
+    k1.setup_keep_acc();
+    k1.mainloop();
+    k1.epilogue();
+}
+
 static thread_local char g_dcfg[96] = "";
 const char* conv_dma_last_config() { return g_dcfg; }
 
@@ -672,40 +712,14 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
 
 #define DCASE(BM, BN, KT, ST, UP, BK, NS) return launch_dma_cfg<BM, BN, KT, ST, UP, BK, NS>(a, s)
 
-// cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
-hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
-    if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || a.xpad < 1 || a.opad < 1 || a.pad < 0 || a.pad > a.xpad) return hipErrorInvalidValue;
-    if (a.voc) {
-        // vocoder resblock convolutions (k 3 / 7 / 11, dilation 1 / 3 / 5; LeakyReLU / running-sum epilogues): one 64 x 128 tile shape,
-        // BK 16 (a K-step = 16 channels x all taps: 6 / 14 / 22 MFMA groups of 8 per wave), 2 stages (the weight tile of k 11 is 45 KB per stage)
-        if (a.stride != 1 || a.ups || a.epi != EPI_NONE || cfg != 0) return hipErrorInvalidValue;
-        if (a.ph_Tout) {      // upsampler: 2 taps per phase
-            if (a.KT != 2 || a.dil != 1 || a.pad != 1 || a.res || a.acc_in || a.out_plain || a.out_div != 1.0f || a.ph_log2 < 0 || a.ph_log2 > 4 ||
-                a.ph_Cout << a.ph_log2 != a.Co || a.ph_Cout % 8)
-                return hipErrorInvalidValue;
-            return launch_dma_cfg<64, 128, 2, 1, false, 16, 2, 1, true>(a, s);
-        }
-#define VCASE(KT_, D_) if (a.KT == KT_ && a.dil == D_) return launch_dma_cfg<64, 128, KT_, 1, false, 16, 2, D_, true>(a, s)
-        // one M-block (64 output channels) and 11 taps: a 256-frame tile amortises the 45 KB weight tile over twice the columns
-        // (measured 104 -> 114 TFLOP/s with the residual epilogue; k 3 / k 7 lose 7 % on the wide tile)
-        if (a.Mp == 64 && a.KT == 11 && a.To >= 1024) {
-#define WCASE(D_) if (a.dil == D_) return launch_dma_cfg<64, 256, 11, 1, false, 16, 2, D_, true>(a, s)
-            WCASE(1); WCASE(3); WCASE(5);
-#undef WCASE
-        }
-        VCASE(3, 1); VCASE(3, 3); VCASE(3, 5); VCASE(7, 1); VCASE(7, 3); VCASE(7, 5); VCASE(11, 1); VCASE(11, 3); VCASE(11, 5);
-#undef VCASE
-        return hipErrorInvalidValue;
-    }
-    if (a.dil != 1 || a.act_slope != 0.f || a.acc_in || a.out_div != 1.0f || a.ph_Tout) return hipErrorInvalidValue;      // vocoder-only features
-    if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
+// tile shape / K-step / ring depth of one launch (cfg = 0: the measured rules below)
+static void dma_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst) {
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     // The tile shape fixes the order of the K reduction, so it must not depend on the batch size: an utterance's result is then
     // bit-identical for any batch split.  Grid sizes are therefore judged at the nominal per-GPU batch of
     // BASELINE.json (16 utterances), whatever a.B is.
     constexpr long long kNominalBatch = 16;
     auto blocks = [&](int bm, int bn) -> long long { return (a.Mp % bm) ? -1 : (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * kNominalBatch; };
-    int bm, bn, bk, nst;
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
     } else if (a.stride == 1 && !a.ups && a.epi != EPI_GEGLU && k32 && (blocks(64, 64) <= 256 || (blocks(64, 64) < 512 && blocks(64, 64) % 256))) {
@@ -759,6 +773,83 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
         // timing and nothing else -- the bit-identity between B = 1 and batched results holds.
         if (bm == 128 && bn == 128 && (long long)(a.Mp / 128) * ((a.To + 127) / 128) * a.B < 192) bn = 64;
     }
+}
+
+template <int BM, int BN, int BK3, int BK1, int NST>
+static hipError_t launch_pair_cfg(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
+    using Cfg = PairCfg<BM, BN, BK3, BK1, NST>;
+    const int nN = (a1.To + BN - 1) / BN;
+    dim3 grid((a1.Mp / BM) * nN, a1.B);
+    auto kern = conv_dma_pair_kernel<BM, BN, BK3, BK1, NST>;
+    if (Cfg::LDS_BYTES > 48 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
+        if (e != hipSuccess) return e;
+    }
+    snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, grid.x, grid.y, Cfg::LDS_BYTES);
+    DmaPairArgs pp{a3, a1};
+    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, pp);
+    return hipGetLastError();
+}
+
+// fused variant code for the pair, 0 = none: (BM << 16) | (BN << 8) | BK1
+static int pair_variant(const DmaConvArgs& a3, const DmaConvArgs& a1) {
+    auto plain = [](const DmaConvArgs& a) {
+        return !a.voc && a.stride == 1 && !a.ups && a.dil == 1 && a.epi == EPI_NONE && a.xpad == 1 && a.opad == 1 && !a.ln_part && !a.ph_Tout && a.act_slope == 0.f &&
+               !a.acc_in && a.out_div == 1.0f && a.Ci % 16 == 0 && a.C1 % 16 == 0 && a.Mp % 64 == 0 && a.B > 0 && a.To > 0;
+    };
+    if (!plain(a3) || !plain(a1) || a3.KT != 3 || a3.pad != 1 || a1.KT != 1 || a1.pad != 0 || a3.Mp != a1.Mp || a3.To != a1.To || a3.B != a1.B ||
+        a3.Tsrc != a1.Tsrc || a1.res || a1.out_plain || a1.plain_from < a1.Cout || a1.lnpart_out)
+        return 0;
+    int bm, bn, bk, nst;
+    dma_pick(a3, 0, bm, bn, bk, nst);      // the k 3 half carries most of the work: its tile
+    const bool k3_32 = (a3.Ci % 32 == 0) && (a3.C1 % 32 == 0);
+    const bool k1_64 = (a1.Ci % 64 == 0) && (a1.C1 % 64 == 0), k1_32 = (a1.Ci % 32 == 0) && (a1.C1 % 32 == 0);
+    if (!k3_32 || bk != 32 || nst != 2 || !k1_32 || bn != 64 || (bm != 32 && bm != 64)) return 0;
+    return (bm << 16) | (bn << 8) | (k1_64 ? 64 : 32);
+}
+bool conv_dma_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1) { return pair_variant(a3, a1) != 0; }
+
+hipError_t launch_conv_dma_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
+    switch (pair_variant(a3, a1)) {
+        case (32 << 16) | (64 << 8) | 64: return launch_pair_cfg<32, 64, 32, 64, 2>(a3, a1, s);
+        case (32 << 16) | (64 << 8) | 32: return launch_pair_cfg<32, 64, 32, 32, 2>(a3, a1, s);
+        case (64 << 16) | (64 << 8) | 64: return launch_pair_cfg<64, 64, 32, 64, 2>(a3, a1, s);
+        case (64 << 16) | (64 << 8) | 32: return launch_pair_cfg<64, 64, 32, 32, 2>(a3, a1, s);
+        default: return hipErrorNotSupported;
+    }
+}
+
+// cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
+hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
+    if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || a.xpad < 1 || a.opad < 1 || a.pad < 0 || a.pad > a.xpad) return hipErrorInvalidValue;
+    if (a.voc) {
+        // vocoder resblock convolutions (k 3 / 7 / 11, dilation 1 / 3 / 5; LeakyReLU / running-sum epilogues): one 64 x 128 tile shape,
+        // BK 16 (a K-step = 16 channels x all taps: 6 / 14 / 22 MFMA groups of 8 per wave), 2 stages (the weight tile of k 11 is 45 KB per stage)
+        if (a.stride != 1 || a.ups || a.epi != EPI_NONE || cfg != 0) return hipErrorInvalidValue;
+        if (a.ph_Tout) {      // upsampler: 2 taps per phase
+            if (a.KT != 2 || a.dil != 1 || a.pad != 1 || a.res || a.acc_in || a.out_plain || a.out_div != 1.0f || a.ph_log2 < 0 || a.ph_log2 > 4 ||
+                a.ph_Cout << a.ph_log2 != a.Co || a.ph_Cout % 8)
+                return hipErrorInvalidValue;
+            return launch_dma_cfg<64, 128, 2, 1, false, 16, 2, 1, true>(a, s);
+        }
+#define VCASE(KT_, D_) if (a.KT == KT_ && a.dil == D_) return launch_dma_cfg<64, 128, KT_, 1, false, 16, 2, D_, true>(a, s)
+        // one M-block (64 output channels) and 11 taps: a 256-frame tile amortises the 45 KB weight tile over twice the columns
+        // (measured 104 -> 114 TFLOP/s with the residual epilogue; k 3 / k 7 lose 7 % on the wide tile)
+        if (a.Mp == 64 && a.KT == 11 && a.To >= 1024) {
+#define WCASE(D_) if (a.dil == D_) return launch_dma_cfg<64, 256, 11, 1, false, 16, 2, D_, true>(a, s)
+            WCASE(1); WCASE(3); WCASE(5);
+#undef WCASE
+        }
+        VCASE(3, 1); VCASE(3, 3); VCASE(3, 5); VCASE(7, 1); VCASE(7, 3); VCASE(7, 5); VCASE(11, 1); VCASE(11, 3); VCASE(11, 5);
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
+    if (a.dil != 1 || a.act_slope != 0.f || a.acc_in || a.out_div != 1.0f || a.ph_Tout) return hipErrorInvalidValue;      // vocoder-only features
+    if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
+    int bm, bn, bk, nst;
+    dma_pick(a, cfg, bm, bn, bk, nst);
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     if (a.Mp % bm) return hipErrorInvalidValue;
     if ((bk == 64 && !k64) || (bk == 32 && !k32)) bk = 16;

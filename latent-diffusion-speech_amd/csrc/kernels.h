@@ -94,6 +94,13 @@ struct DmaConvArgs {
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
+// Resnet tail in one launch (reference resnet.py:636-641): out = conv2_k3(h) + shortcut_1x1([x ; skip]) + bias.  `a3` carries the k 3
+// convolution's sources / weights (its epilogue fields are ignored), `a1` the 1x1 shortcut's sources / weights AND the epilogue
+// (bias = the two biases added on the host, GroupNorm partials, output).  Both reductions run into the same accumulators: one
+// launch and one K4P round trip less per resnet that changes its width.  hipErrorNotSupported: no fused variant for these shapes
+// (the caller launches the two convolutions separately).
+hipError_t launch_conv_dma_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s);
+bool conv_dma_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1);
 const char* conv_dma_last_config();
 
 // ---------------------------------------------------------------------------------------------

@@ -362,9 +362,7 @@ struct DOpt {
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
 };
-static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B,
-                     hipStream_t st) {
-    DmaConvArgs a;
+static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, DmaConvArgs& a) {
     memset(&a, 0, sizeof(a));
     if (C1 + C2 != W.Ci) return fail(LDS_EINVAL, "dconv: input channels %d+%d != %d", C1, C2, W.Ci);
     a.x1 = x1; a.x2 = x2 ? x2 : x1; a.C1 = C1; a.C2 = C2; a.Tsrc = Tsrc;
@@ -380,6 +378,13 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
     a.To = (Tin + 2 * o.pad - o.dil * (W.K - 1) - 1) / o.stride + 1;
     a.B = B;
+    return LDS_OK;
+}
+static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B,
+                     hipStream_t st) {
+    DmaConvArgs a;
+    int rc = fill_dconv(W, x1, C1, x2, C2, Tsrc, o, out, B, a);
+    if (rc != LDS_OK) return rc;
     const double flops = 2.0 * B * (double)a.To * (double)W.Co * (double)W.Ci * (double)W.K;
     const double bytes = 4.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
     hipError_t e;
@@ -402,6 +407,42 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
                     o.stride, o.ups, a.To);
     return LDS_OK;
 }
+// conv2 (k 3 over h) and the 1x1 shortcut (over the block input x1 ; x2) of a resnet in one launch: out = W2 * h + Ws * [x1 ; x2] + bias.
+// Returns 1 when there is no fused variant for these shapes (the caller then runs the two convolutions separately).
+static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, const float* x1, int C1, const float* x2, int C2, int T, const float* bias_pair,
+                          float2* gnpart_out, float* out, int B, hipStream_t st) {
+    DmaConvArgs a3, a1;
+    DOpt o3;
+    o3.pad = 1;
+    int rc = fill_dconv(W3, h, W3.Ci, nullptr, 0, T, o3, out, B, a3);
+    if (rc != LDS_OK) return rc;
+    DOpt o1;
+    o1.gnpart_out = gnpart_out;
+    rc = fill_dconv(W1, x1, C1, x2, C2, T, o1, out, B, a1);
+    if (rc != LDS_OK) return rc;
+    a3.bias = nullptr;
+    a1.bias = bias_pair;
+    const double flops = 2.0 * B * (double)a1.To * (double)W3.Co * ((double)W3.Ci * 3.0 + (double)W1.Ci);
+    const double bytes = 4.0 * ((double)B * (W3.Ci + W1.Ci) * T + (double)W3.Co * (3.0 * W3.Ci + W1.Ci) + (double)B * a1.Cout * a1.To);
+    if (!conv_dma_pair_applies(a3, a1)) return 1;
+    hipError_t e;
+    {
+        ProfScope ps(st, "conv_dma", flops, bytes);
+        e = launch_conv_dma_pair(a3, a1, st);
+        if (ps.on) {
+            std::string cfgs(conv_dma_last_config());
+            std::string nm = "conv_dma<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
+                char sh[96];
+                snprintf(sh, sizeof(sh), " Ci%d+%d Co%d K3+1 To%d", W3.Ci, W1.Ci, W3.Co, a1.To);
+                nm += sh;
+            }
+            ps.rename(nm);
+        }
+    }
+    if (e != hipSuccess) return fail(LDS_EHIP, "conv_dma pair launch failed (%s): Co %d Ci %d+%d To %d", hipGetErrorString(e), W3.Co, W3.Ci, W1.Ci, a1.To);
+    return LDS_OK;
+}
 
 // ================================================================================================
 // UNet
@@ -410,6 +451,7 @@ struct ResnetW {
     int cin = 0, cout = 0;
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
     ConvW conv1, conv2, sc;
+    float* bias_pair = nullptr;      // conv2.bias + conv_shortcut.bias per packed row (the fused conv2 + shortcut launch)
     bool has_sc = false;
     int temb_off = 0;
 };
@@ -466,6 +508,10 @@ static bool load_resnet(lds_unet* u, Tensors& T, const std::string& p, int cin, 
         const float* ws = T.get(p + "conv_shortcut.weight", (int64_t)cout * cin);
         const float* bs = T.get(p + "conv_shortcut.bias", cout);
         if (!ws || !bs || !pack_conv(o, ws, bs, cout, cin, 1, r.sc)) return false;
+        std::vector<float> bp(r.conv2.Mp, 0.f);
+        for (int co = 0; co < cout; ++co) bp[co] = c2b[co] + bs[co];
+        r.bias_pair = o.upload(bp);
+        if (!r.bias_pair) return false;
     }
     r.temb_off = (int)tpb.size();
     tpw.insert(tpw.end(), tw, tw + (size_t)2 * cout * u->temb);
@@ -777,14 +823,17 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     DOpt o1;
     o1.pad = 1; o1.gnpart_out = w.gp(w.h1);
     LDS_TRY(run_dconv(r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
-    const float* res = x1;
-    if (r.has_sc) {
-        DOpt os;
-        LDS_TRY(run_dconv(r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));   // skip-concat on read: second source pointer
-        res = w.sc;
-    }
     HIP_TRY(launch_gn_stream(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr,
                              w.gno, B, st));
+    const float* res = x1;
+    if (r.has_sc) {
+        // the shortcut rides in conv2's launch (second reduction into the same accumulators; skip-concat on read: two source pointers)
+        const int rc = run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st);
+        if (rc != 1) return rc;
+        DOpt os;      // no fused variant for these shapes: two launches
+        LDS_TRY(run_dconv(r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));
+        res = w.sc;
+    }
     DOpt o2;
     o2.pad = 1; o2.res = res; o2.gnpart_out = w.gp(out);
     return run_dconv(r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
