@@ -101,7 +101,8 @@ def pmc_mfma_util(kernel_name):
 
 
 class NativeProfiler:
-    """liblds's HIP-event profiler (one event pair per launch on the launch stream)."""
+    """liblds's HIP-event profiler: one event pair per launch on the launch stream; for the conv_dma family the pair is bound to the
+    dispatch itself (hipExtLaunchKernelGGL start / stop slots), so those durations are the kernels' own begin-to-end times."""
 
     def __init__(self, detail=False):
         self.detail = detail

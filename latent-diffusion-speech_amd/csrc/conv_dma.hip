@@ -23,6 +23,8 @@
 #include "k4p.h"
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -706,7 +708,9 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
     }
     if (!VOC) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x, grid.y, Cfg::LDS_BYTES);
     else snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d D%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, DIL, grid.x, grid.y, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
+    hipEvent_t e0, e1;
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, a);      // bench.py's roofline leg
+    else hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
@@ -788,7 +792,9 @@ static hipError_t launch_pair_cfg(const DmaConvArgs& a3, const DmaConvArgs& a1, 
     }
     snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, grid.x, grid.y, Cfg::LDS_BYTES);
     DmaPairArgs pp{a3, a1};
-    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, pp);
+    hipEvent_t e0, e1;
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, pp);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, pp);
     return hipGetLastError();
 }
 

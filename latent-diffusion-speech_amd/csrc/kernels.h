@@ -171,6 +171,10 @@ hipError_t launch_resample_nearest(const float* in, float* out, int B, int C, in
 // ---------------------------------------------------------------------------------------------
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
 // ---------------------------------------------------------------------------------------------
+// Called by a launcher inside an open ProfScope of this thread: two fresh events for hipExtLaunchKernelGGL's start / stop slots, which
+// the runtime binds to the kernel's own begin / end timestamps (no extra packets on the stream, so neighbouring launches still
+// overlap their dispatch as in an un-instrumented run).  false: no scope is open / the profiler is off -- launch normally.
+bool prof_attach_events(hipEvent_t* start, hipEvent_t* stop);
 // records the thread-local message returned by lds_last_error() and returns `code` (model.hip)
 int set_error(int code, const char* fmt, ...);
 
@@ -178,7 +182,9 @@ struct ProfScope {
     bool on;
     hipStream_t s;
     int idx = -1;
-    ProfScope(hipStream_t st, const char* name, double flops, double bytes);
+    bool attached = false;      // the launch itself carries the two events (prof_attach_events): the destructor records nothing
+    // attachable: the launcher inside the scope will bind the events to its dispatch (prof_attach_events): no event is recorded here
+    ProfScope(hipStream_t st, const char* name, double flops, double bytes, bool attachable = false);
     ~ProfScope();
     void rename(const std::string& n);
 };

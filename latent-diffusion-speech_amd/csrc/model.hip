@@ -76,20 +76,42 @@ static int prof_mark(hipStream_t st) {      // g_prof_mu held
     g_prof_ev.push_back(e);
     return (int)g_prof_ev.size() - 1;
 }
-lds::ProfScope::ProfScope(hipStream_t st, const char* name, double flops, double bytes) : on(g_prof_level.load(std::memory_order_relaxed) != 0), s(st) {
+static thread_local lds::ProfScope* tl_prof_open = nullptr;
+bool lds::prof_attach_events(hipEvent_t* start, hipEvent_t* stop) {
+    lds::ProfScope* ps = tl_prof_open;
+    if (!ps || !ps->on || ps->attached) return false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (ps->idx < 0 || ps->idx >= (int)g_prof.size()) return false;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return false;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return false; }
+    g_prof_ev.push_back(e0);
+    g_prof[ps->idx].ia = (int)g_prof_ev.size() - 1;      // (the event marked at the scope's start is simply not read)
+    g_prof_ev.push_back(e1);
+    g_prof[ps->idx].ib = (int)g_prof_ev.size() - 1;
+    ps->attached = true;
+    g_prof_last_stop = -1;                               // a chained neighbour must not reuse a bound event as its start mark
+    *start = e0; *stop = e1;
+    return true;
+}
+lds::ProfScope::ProfScope(hipStream_t st, const char* name, double flops, double bytes, bool attachable) : on(g_prof_level.load(std::memory_order_relaxed) != 0), s(st) {
     if (!on) return;
+    tl_prof_open = this;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.name = name; r.flops = flops; r.bytes = bytes; r.ib = -1;
-    r.ia = (g_prof_chain && g_prof_last_stop >= 0 && g_prof_last_stream == st) ? g_prof_last_stop : prof_mark(st);
-    if (r.ia < 0) { on = false; return; }
+    r.ia = attachable ? -1 : ((g_prof_chain && g_prof_last_stop >= 0 && g_prof_last_stream == st) ? g_prof_last_stop : prof_mark(st));
+    if (r.ia < 0 && !attachable) { on = false; return; }
+    if (attachable) g_prof_last_stop = -1;      // no stream event here: a chained neighbour records its own start
     g_prof.push_back(r);
     idx = (int)g_prof.size() - 1;
 }
 lds::ProfScope::~ProfScope() {
-    if (!on) return;
+    if (tl_prof_open == this) tl_prof_open = nullptr;
+    if (!on || attached) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (idx < 0 || idx >= (int)g_prof.size()) return;      // the profiler was reset while this scope was open
+    if (g_prof[idx].ia < 0) return;                         // attachable scope whose launcher took no events: the record stays empty
     g_prof[idx].ib = prof_mark(s);
     g_prof_last_stop = g_prof[idx].ib;
     g_prof_last_stream = s;
@@ -130,6 +152,7 @@ extern "C" int lds_prof_summary(char* buf, size_t cap) {
     std::map<std::string, Agg> agg;
     for (auto& r : g_prof) {
         float ms = 0.f;
+        if (r.ia < 0 && r.ib < 0) continue;      // an attachable scope whose launcher did not take the events (nothing was launched)
         if (r.ib < 0 || hipEventSynchronize(g_prof_ev[r.ib]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[r.ia], g_prof_ev[r.ib]) != hipSuccess)
             return fail(LDS_EHIP, "profiler event read failed");
         Agg& a = agg[r.name];
@@ -389,7 +412,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     const double bytes = 4.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
     hipError_t e;
     {
-        ProfScope ps(st, "conv_dma", flops, bytes);
+        ProfScope ps(st, "conv_dma", flops, bytes, true);
         e = launch_conv_dma(a, o.cfg, st);
         if (ps.on) {
             std::string cfgs(conv_dma_last_config());
@@ -427,7 +450,7 @@ static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, cons
     if (!conv_dma_pair_applies(a3, a1)) return 1;
     hipError_t e;
     {
-        ProfScope ps(st, "conv_dma", flops, bytes);
+        ProfScope ps(st, "conv_dma", flops, bytes, true);
         e = launch_conv_dma_pair(a3, a1, st);
         if (ps.on) {
             std::string cfgs(conv_dma_last_config());
