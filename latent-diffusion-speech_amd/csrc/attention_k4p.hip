@@ -14,6 +14,8 @@
 #include "k4p.h"
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <math.h>
 
 namespace lds {
@@ -256,7 +258,9 @@ static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B
         if (e != hipSuccess) return e;
     }
     constexpr int QPB = NW / KS * 32;       // queries per workgroup
-    hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);
+    hipEvent_t e0, e1;
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, e0, e1, 0, qk, vt, out, C, T, scale);
+    else hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);
     return hipGetLastError();
 }
 
@@ -275,7 +279,7 @@ static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B,
 
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
     if (C % heads) return hipErrorInvalidValue;
-    ProfScope ps(s, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T);
+    ProfScope ps(s, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
     switch (C / heads) {
         case 32: return launch_dk<32>(qk, vt, out, B, C, T, heads, s);
         case 48: return launch_dk<48>(qk, vt, out, B, C, T, heads, s);
