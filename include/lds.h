@@ -14,9 +14,12 @@
  *   - every pointer marked "dev" is device memory owned by the caller (a torch tensor);
  *     "host" pointers are read during the call only.
  *   - activations are fp32, channel-major [B, C, T] with the frame axis contiguous.
- *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it and
- *     never synchronises.  Handles are immutable after create, so calls on different
- *     streams are safe as long as each has its own workspace.
+ *   - `stream` is a hipStream_t passed as void*; the forward / run calls only enqueue work on it and
+ *     never synchronise the device (host arrays they are handed -- the sampler's table -- are copied into
+ *     the launches' kernel arguments during the call).  Exceptions, documented at the function:
+ *     lds_lm_generate polls for EOS, *_create upload weights, lds_prof_summary reads events.
+ *     Handles are immutable after create, so calls on different streams are safe as long as each
+ *     has its own workspace.
  *   - return value 0 = ok, negative LDS_E* on error; lds_last_error() gives the message
  *     (thread-local).  Nothing throws or aborts.
  */
@@ -176,54 +179,16 @@ int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int max_length, 
 int lds_prof_enable(int on);
 int lds_prof_summary(char* buf, size_t cap);
 
-/* ---- single-op entry points (used by the parity tests to check each kernel alone) ----------- */
-typedef struct {                        /* the generic convolution (vocoder / front end path, conv_gemm)   */
-    const float* x1; const float* x2;   /* dev inputs [B,C1,Tsrc], [B,C2,Tsrc] (x2 may be NULL)  */
-    int C1, C2, Tsrc;
-    const float* w;                     /* host, reference layout [Co, C1+C2, K]                  */
-    const float* bias;                  /* host [Co] or NULL                                      */
-    int Co, K, pad, dil;
-    int act_in;                         /* 0 none, 2 LeakyReLU(slope) on the input                */
-    float slope;
-    const float* res;                   /* dev [B,Co,To] or NULL                                  */
-    int epilogue;                       /* 0 none, 2 tanh                                         */
-    int tile;                           /* 0 auto, else BM*1000+BN                                */
-} lds_conv_test;
-int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream);
-/* ---- the UNet's K4P path, one op at a time (plain tensors in/out; layout conversion happens on the device) ---- */
-typedef struct {
-    const float* x1; const float* x2;   /* dev inputs [B,C1,T], [B,C2,T] (x2 may be NULL)                 */
-    int C1, C2, T;
-    const float* w; const float* bias;  /* host, reference layout [Co, C1+C2, K] / [Co]                   */
-    int Co, K, stride, pad, ups;
-    const float* res;                   /* dev [B,Cout,To] or NULL                                        */
-    int epilogue;                       /* 0 none, 1 GEGLU                                                */
-    int plain_out;                      /* 1: the kernel writes frame-major output directly               */
-    int v_split;                        /* QKV: last third of the channels frame-major (1) or in attention's VT layout with head dim v_split (> 1) */
-    int cfg;                            /* 0 auto, else BM*1000000 + BN*1000 + BK*10 + NST                */
-} lds_dconv_test;
-int lds_test_dconv(const lds_dconv_test* a, float* out, float* lnpart, int B, void* stream);
-int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
-                    void* stream);
-int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
-                      const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
-/* average time of one streaming-GroupNorm launch on zero-filled tensors (tools/bench_gn.py) */
-int lds_bench_gn_stream(int C1, int C2, int T, int B, int iters, float* ms_out, void* stream);
-/* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
- * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
-int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,
-                          int groups, int silu, float* mid, float* out, int B, int C, int Co, int T, int cfg, void* stream);
-int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
-                          float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
-/* one residual step of a vocoder ResBlock1 on the K4P / LDS-DMA path: out = c2(lrelu(c1(lrelu(x)))) + x (reference models.py:186-192);
- * mode 0 plain output, 1 raw + LeakyReLU'd K4P outputs (returned plain in out / out_act), 2 running sum out = (acc + y) / div */
-int lds_test_voc_step(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil, int mode,
-                      const float* acc, float div, float* out, float* out_act, int B, void* stream);
-/* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
-int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
-int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
-                            float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
-                            float in_slope, void* stream);
+/* ---- exact-fp32 vs fp32-equivalent split-bf16 GEMMs (csrc/conv_bf3.hip, csrc/k8b3.h) ------------------------------------
+ * mode 0 (default): every convolution / linear layer of the UNet on the exact-fp32 MFMA (a k-ordered fmaf chain).
+ * mode 1: the same layers on the bf16 MFMA with every fp32 operand held as three bf16 terms (lossless) and six bf16 products per
+ * fp32 product, fp32 accumulate: same tolerances against the reference (tests/test_gpu_bf3.py, profiles/r03_split_bf16_probe.json).
+ * The first switch to mode 1 packs the split weights (host work + upload); later switches only flip the flag.  Not thread-safe
+ * against concurrent forwards on the same handle. */
+#define LDS_GEMM_F32 0
+#define LDS_GEMM_SPLIT_BF16 1
+int lds_unet_set_gemm_mode(lds_unet* u, int mode);
+int lds_unet_get_gemm_mode(const lds_unet* u);
 
 #ifdef __cplusplus
 }

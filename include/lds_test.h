@@ -1,0 +1,79 @@
+/*
+ * liblds.so -- single-op test and micro-benchmark entry points.  NOT part of the drop-in boundary (include/lds.h): they exist so
+ * that tests/ can check each kernel alone against the oracle and tools/ can time one launch.  Every call here allocates its own
+ * temporaries and synchronises the stream before returning.
+ */
+#ifndef LDS_TEST_H
+#define LDS_TEST_H
+
+#include "lds.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- single-op entry points (used by the parity tests to check each kernel alone) ----------- */
+typedef struct {                        /* the generic convolution (vocoder / front end path, conv_gemm)   */
+    const float* x1; const float* x2;   /* dev inputs [B,C1,Tsrc], [B,C2,Tsrc] (x2 may be NULL)  */
+    int C1, C2, Tsrc;
+    const float* w;                     /* host, reference layout [Co, C1+C2, K]                  */
+    const float* bias;                  /* host [Co] or NULL                                      */
+    int Co, K, pad, dil;
+    int act_in;                         /* 0 none, 2 LeakyReLU(slope) on the input                */
+    float slope;
+    const float* res;                   /* dev [B,Co,To] or NULL                                  */
+    int epilogue;                       /* 0 none, 2 tanh                                         */
+    int tile;                           /* 0 auto, else BM*1000+BN                                */
+} lds_conv_test;
+int lds_test_conv(const lds_conv_test* a, float* out, int B, void* stream);
+/* ---- the UNet's K4P path, one op at a time (plain tensors in/out; layout conversion happens on the device) ---- */
+typedef struct {
+    const float* x1; const float* x2;   /* dev inputs [B,C1,T], [B,C2,T] (x2 may be NULL)                 */
+    int C1, C2, T;
+    const float* w; const float* bias;  /* host, reference layout [Co, C1+C2, K] / [Co]                   */
+    int Co, K, stride, pad, ups;
+    const float* res;                   /* dev [B,Cout,To] or NULL                                        */
+    int epilogue;                       /* 0 none, 1 GEGLU                                                */
+    int plain_out;                      /* 1: the kernel writes frame-major output directly               */
+    int v_split;                        /* QKV: last third of the channels frame-major (1) or in attention's VT layout with head dim v_split (> 1) */
+    int cfg;                            /* 0 auto, else BM*1000000 + BN*1000 + BK*10 + NST                */
+} lds_dconv_test;
+int lds_test_dconv(const lds_dconv_test* a, float* out, float* lnpart, int B, void* stream);
+int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int iters, float* ms_out, char* cfg_out, size_t cfg_cap,
+                    void* stream);
+int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                      const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
+/* average time of one streaming-GroupNorm launch on zero-filled tensors (tools/bench_gn.py) */
+int lds_bench_gn_stream(int C1, int C2, int T, int B, int iters, float* ms_out, void* stream);
+/* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
+ * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
+int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,
+                          int groups, int silu, float* mid, float* out, int B, int C, int Co, int T, int cfg, void* stream);
+int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta,
+                          float eps, float* mid, float* out, int B, int C, int Co, int T, void* stream);
+/* one residual step of a vocoder ResBlock1 on the K4P / LDS-DMA path: out = c2(lrelu(c1(lrelu(x)))) + x (reference models.py:186-192);
+ * mode 0 plain output, 1 raw + LeakyReLU'd K4P outputs (returned plain in out / out_act), 2 running sum out = (acc + y) / div */
+int lds_test_voc_step(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil, int mode,
+                      const float* acc, float div, float* out, float* out_act, int B, void* stream);
+/* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
+int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
+int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
+                            float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
+                            float in_slope, void* stream);
+
+/* the same single-op entry as lds_test_dconv / lds_bench_dconv through the split-bf16 kernel (conv_bf3.hip): plain tensors are
+ * converted to K8B3 on the device; nprod = bf16 products per fp32 product (6 = the product path; 3 and 9 exist for the error study
+ * of tools/split_bf16_probe.py on the 128 x 128 x BK32 1x1 tile only) */
+int lds_test_dconv_bf3(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, void* stream);
+int lds_bench_dconv_bf3(const lds_dconv_test* a, float* out, int B, int iters, int nprod, float* ms_out, char* cfg_out, size_t cfg_cap,
+                        void* stream);
+/* plain [B,C,T] -> K8B3 -> plain: must return the input bit for bit (the three-term split is lossless) */
+int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream);
+/* GroupNorm(+scale/shift)(+SiLU) through the K8B3 streaming pass (statistics from gn_partials_bf3) */
+int lds_test_gn_apply_bf3(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                          const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDS_TEST_H */

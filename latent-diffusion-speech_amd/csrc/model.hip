@@ -2,6 +2,8 @@
 // and the vocoder, exported through the C ABI in include/lds.h.  Everything here only enqueues
 // kernels on the caller's stream; no allocation or synchronisation happens after *_create.
 #include "../../include/lds.h"
+#include "../../include/lds_test.h"
+#include "k8b3.h"
 #include "kernels.h"
 
 #include <math.h>
@@ -191,6 +193,16 @@ struct Owner {
         ptrs.push_back(d);
         return (float*)d;
     }
+    void* upload_bytes(const void* h, size_t n) {
+        void* d = nullptr;
+        if (hipMalloc(&d, n) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return nullptr;
+        }
+        ptrs.push_back(d);
+        return d;
+    }
 };
 
 struct Tensors {
@@ -212,6 +224,7 @@ struct ConvW {
     float* w = nullptr;
     float* bias = nullptr;
     int Co = 0, Ci = 0, K = 1, Mp = 0;
+    void* w3 = nullptr;      // the same weights as three bf16 planes [KT][Ci/8][3][Mp][8] (split-bf16 path, conv_bf3.hip)
 };
 
 static int round_mp(int Co) { return Co <= 32 ? 32 : (Co + 63) / 64 * 64; }
@@ -219,6 +232,32 @@ static int round_mp(int Co) { return Co <= 32 ? 32 : (Co + 63) / 64 * 64; }
 // packed weight index (see conv_gemm.hip, "k-interleaved tiles"): [tap][k/8][k%2][Mp][(k%8)/2]
 static inline size_t widx(int tap, int k, int m, int Ci, int Mp) {
     return ((((size_t)tap * (Ci / 8) + k / 8) * 2 + (k & 1)) * Mp + m) * 4 + ((k & 7) >> 1);
+}
+
+// Split-bf16 twin of a packed fp32 weight set: every value as three bf16 terms (k8b3.h), [tap][Ci/8][3][Mp][8].  `get(tap, ci, m)` returns
+// the fp32 weight of packed row m.
+template <typename F>
+static bool pack_bf3(Owner& o, int K, int Ci, int Mp, F get, ConvW& out) {
+    std::vector<uint16_t> p((size_t)K * Ci * Mp * 3, 0);
+    for (int tap = 0; tap < K; ++tap)
+        for (int ci = 0; ci < Ci; ++ci)
+            for (int m = 0; m < Mp; ++m) {
+                uint16_t t3[3];
+                split3_host(get(tap, ci, m), t3);
+                for (int pl = 0; pl < 3; ++pl) p[((((size_t)tap * (Ci / 8) + ci / 8) * 3 + pl) * Mp + m) * 8 + (ci & 7)] = t3[pl];
+            }
+    out.w3 = o.upload_bytes(p.data(), p.size() * sizeof(uint16_t));
+    return out.w3 != nullptr;
+}
+static bool pack_bf3_from_packed(Owner& o, const std::vector<float>& p, int K, int Ci, int Mp, ConvW& out) {
+    return pack_bf3(o, K, Ci, Mp, [&](int tap, int ci, int m) { return p[widx(tap, ci, m, Ci, Mp)]; }, out);
+}
+// split-bf16 twin of an already uploaded weight set (read back from the device: the packers keep no host copy)
+static bool make_bf3_twin(Owner& o, ConvW& W) {
+    if (W.w3 || !W.w) return W.w3 != nullptr;
+    std::vector<float> p((size_t)W.K * W.Ci * W.Mp);
+    if (hipMemcpy(p.data(), W.w, p.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return pack_bf3_from_packed(o, p, W.K, W.Ci, W.Mp, W);
 }
 
 // reference layout w[Co][Ci][K] (or [Co][Ci] for Linear) -> packed
@@ -384,6 +423,7 @@ struct DOpt {
     int ph_log2 = 0, ph_tpad = 0, ph_Tout = 0;      // polyphase ConvTranspose output (kernels.h)
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     int cfg = 0;
+    int out_f32 = 0;      // split-bf16 path: the K4P-range output channels stay fp32 K4P (q / k for the attention kernel)
 };
 static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, DmaConvArgs& a) {
     memset(&a, 0, sizeof(a));
@@ -428,6 +468,38 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     if (e != hipSuccess)
         return fail(LDS_EHIP, "conv_dma launch failed (%s): Co %d Ci %d K %d stride %d ups %d To %d", hipGetErrorString(e), W.Co, W.Ci, W.K,
                     o.stride, o.ups, a.To);
+    return LDS_OK;
+}
+// the same operator on the split-bf16 path (conv_bf3.hip): K8B3 activations, W.w3 weights
+static int run_dconv_bf3(const ConvW& W, const void* x1, int C1, const void* x2, int C2, int Tsrc, const DOpt& o, void* out, int B, hipStream_t st,
+                         int nprod = 6) {
+    DmaConvArgs a;
+    int rc = fill_dconv(W, (const float*)x1, C1, (const float*)x2, C2, Tsrc, o, (float*)out, B, a);
+    if (rc != LDS_OK) return rc;
+    if (!W.w3) return fail(LDS_EINVAL, "split-bf16 weights were not packed for this layer");
+    a.w = (const float*)W.w3;
+    a.x2 = (const float*)x2;      // null = one source (fill_dconv aliases x1 for the fp32 kernel)
+    a.out_f32 = o.out_f32;
+    const double flops = 2.0 * B * (double)a.To * (double)W.Co * (double)W.Ci * (double)W.K;
+    const double bytes = 6.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
+    hipError_t e;
+    {
+        ProfScope ps(st, "conv_bf3", flops, bytes, true);
+        e = launch_conv_bf3(a, o.cfg, nprod, st);
+        if (ps.on) {
+            std::string cfgs(conv_bf3_last_config());
+            std::string nm = "conv_bf3<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
+                char sh[96];
+                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d To%d%s", W.Ci, W.Co, W.K, a.To, o.res ? " +res" : "");
+                nm += sh;
+            }
+            ps.rename(nm);
+        }
+    }
+    if (e != hipSuccess)
+        return fail(LDS_EHIP, "conv_bf3 launch failed (%s): Co %d Ci %d K %d stride %d ups %d To %d cfg %d", hipGetErrorString(e), W.Co, W.Ci, W.K, o.stride,
+                    o.ups, a.To, o.cfg);
     return LDS_OK;
 }
 // conv2 (k 3 over h) and the 1x1 shortcut (over the block input x1 ; x2) of a resnet in one launch: out = W2 * h + Ws * [x1 ; x2] + bias.
@@ -503,6 +575,8 @@ struct lds_unet {
     TfmW mid_t;
     std::vector<UpBlk> up;
     int max_ci = 0;
+    int gemm_mode = LDS_GEMM_F32;      // LDS_GEMM_SPLIT_BF16: every conv / linear through conv_bf3 (lds_unet_set_gemm_mode)
+    bool bf3_packed = false;
 };
 
 static float* up_vec(Owner& o, const float* p, int64_t n) {
@@ -760,6 +834,41 @@ extern "C" int lds_unet_create(const lds_unet_cfg* cfg, int n, const char* const
 }
 
 extern "C" void lds_unet_destroy(lds_unet* u) { delete u; }
+
+// split-bf16 twins of every weight set the forward pass uses (first switch to LDS_GEMM_SPLIT_BF16 only)
+static bool unet_pack_bf3(lds_unet* u) {
+    Owner& o = u->own;
+    bool ok = true;
+    auto res = [&](ResnetW& r) { ok = ok && make_bf3_twin(o, r.conv1) && make_bf3_twin(o, r.conv2) && (!r.has_sc || make_bf3_twin(o, r.sc)); };
+    auto tfm = [&](TfmW& t) {
+        ok = ok && make_bf3_twin(o, t.proj_in) && make_bf3_twin(o, t.qkv[0]) && make_bf3_twin(o, t.qkv[1]) && make_bf3_twin(o, t.o[0]) && make_bf3_twin(o, t.o[1]) &&
+             make_bf3_twin(o, t.ff1) && make_bf3_twin(o, t.ff2_out);
+    };
+    ok = make_bf3_twin(o, u->conv_in) && make_bf3_twin(o, u->conv_in_x) && make_bf3_twin(o, u->conv_in_c) && make_bf3_twin(o, u->conv_out);
+    for (auto& d : u->down) {
+        for (auto& r : d.res) res(r);
+        for (auto& t : d.att) tfm(t);
+        if (d.has_down) ok = ok && make_bf3_twin(o, d.down);
+    }
+    res(u->mid_r0); tfm(u->mid_t); res(u->mid_r1);
+    for (auto& b : u->up) {
+        for (auto& r : b.res) res(r);
+        for (auto& t : b.att) tfm(t);
+        if (b.has_up) ok = ok && make_bf3_twin(o, b.up);
+    }
+    return ok;
+}
+extern "C" int lds_unet_set_gemm_mode(lds_unet* u, int mode) {
+    if (!u || (mode != LDS_GEMM_F32 && mode != LDS_GEMM_SPLIT_BF16)) return fail(LDS_EINVAL, "bad argument");
+    if (mode == LDS_GEMM_SPLIT_BF16 && !u->bf3_packed) {
+        if (u->M % 16 || u->H % 16) return fail(LDS_EINVAL, "split-bf16 mode needs out_dims and n_hidden to be multiples of 16");
+        if (!unet_pack_bf3(u)) return fail(LDS_ENOMEM, "packing the split-bf16 weights failed");
+        u->bf3_packed = true;
+    }
+    u->gemm_mode = mode;
+    return LDS_OK;
+}
+extern "C" int lds_unet_get_gemm_mode(const lds_unet* u) { return u ? u->gemm_mode : LDS_EINVAL; }
 
 static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
 
@@ -1559,33 +1668,40 @@ struct TmpDev {
     float* f(size_t n) { void* d = nullptr; if (hipMalloc(&d, n * sizeof(float) + 65536) != hipSuccess) return nullptr; p.push_back(d); return (float*)d; }
 };
 
-static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream) {
+// bf3 = 1: the same operator through the split-bf16 kernel (K8B3 tensors, conv_bf3.hip) with `nprod` bf16 products per fp32 product
+static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream, int bf3 = 0, int nprod = 6) {
     hipStream_t st = (hipStream_t)stream;
     Owner own;
     TmpDev tmp;
     ConvW W;
     const int Ci = a->C1 + a->C2, T = a->T;
     bool ok = (a->epilogue == EPI_GEGLU) ? pack_geglu(own, a->w, a->bias, a->Co, Ci, W) : pack_conv(own, a->w, a->bias, a->Co, Ci, a->K, W);
+    if (ok && bf3) ok = make_bf3_twin(own, W);
     if (!ok) return fail(LDS_ENOMEM, "test dconv: upload failed");
-    float* k1 = tmp.f((size_t)B * a->C1 * (T + 2));
-    float* k2 = a->C2 ? tmp.f((size_t)B * a->C2 * (T + 2)) : nullptr;
+    auto act_floats = [&](int C, int Tl) { return bf3 ? (size_t)B * k8b3_floats(C, Tl) : (size_t)B * C * (Tl + 2); };
+    auto to_act = [&](const float* src, float* dst, int C, int Tl) { return bf3 ? launch_to_k8b3(src, dst, B, C, Tl, C, 0, st) : launch_to_k4p(src, dst, B, C, Tl, C, 0, st); };
+    auto from_act = [&](const float* src, float* dst, int C, int Tl) { return bf3 ? launch_from_k8b3(src, dst, B, C, Tl, st) : launch_from_k4p(src, dst, B, C, Tl, st); };
+    float* k1 = tmp.f(act_floats(a->C1, T));
+    float* k2 = a->C2 ? tmp.f(act_floats(a->C2, T)) : nullptr;
     if (!k1 || (a->C2 && !k2)) return fail(LDS_ENOMEM, "test dconv: alloc failed");
-    HIP_TRY(launch_to_k4p(a->x1, k1, B, a->C1, T, a->C1, 0, st));
-    if (a->C2) HIP_TRY(launch_to_k4p(a->x2, k2, B, a->C2, T, a->C2, 0, st));
+    HIP_TRY(to_act(a->x1, k1, a->C1, T));
+    if (a->C2) HIP_TRY(to_act(a->x2, k2, a->C2, T));
     const int Cout = (a->epilogue == EPI_GEGLU) ? a->Co / 2 : a->Co;
     const int Tin = a->ups ? 2 * T : T;
     const int To = (Tin + 2 * a->pad - (a->K - 1) - 1) / a->stride + 1;
     const int Ck = a->v_split ? (Cout / 3) * 2 : Cout;
     DOpt o;
     o.stride = a->stride; o.pad = a->pad; o.ups = a->ups; o.epi = a->epilogue; o.cfg = a->cfg; o.out_plain = a->plain_out;
+    const bool qk_f32 = bf3 && a->v_split;      // the QKV projection of the split-bf16 path keeps q / k in fp32 K4P for the attention kernel
+    o.out_f32 = qk_f32 ? 1 : 0;
     float* kres = nullptr;
     if (a->res) {
-        kres = tmp.f((size_t)B * Ck * (To + 2));
+        kres = tmp.f(act_floats(Ck, To));
         if (!kres) return fail(LDS_ENOMEM, "alloc");
-        HIP_TRY(launch_to_k4p(a->res, kres, B, Ck, To, Ck, 0, st));
+        HIP_TRY(to_act(a->res, kres, Ck, To));
         o.res = kres;
     }
-    float* kout = a->plain_out ? out : tmp.f((size_t)B * Ck * (To + 2));
+    float* kout = a->plain_out ? out : tmp.f(qk_f32 ? (size_t)B * Ck * (To + 2) : act_floats(Ck, To));
     float* vout = nullptr;
     if (!kout) return fail(LDS_ENOMEM, "alloc");
     const int To4 = (To + 3) & ~3;
@@ -1597,13 +1713,14 @@ static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, i
         if (a->v_split > 1) o.vt_D = a->v_split;      // value third in attention's VT layout with this head dim
     }
     o.lnpart_out = (float2*)lnpart;
-    int r = run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st);
+    auto run = [&]() { return bf3 ? run_dconv_bf3(W, k1, a->C1, k2, a->C2, T, o, kout, B, st, nprod) : run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st); };
+    int r = run();
     if (r == LDS_OK && iters > 0 && ms_out) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
-        for (int i = 0; i < iters && r == LDS_OK; ++i) r = run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st);
+        for (int i = 0; i < iters && r == LDS_OK; ++i) r = run();
         HIP_TRY(hipEventRecord(e1, st));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1612,23 +1729,24 @@ static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, i
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
+    auto from_out = [&](const float* src, float* dst, int C, int Tl) { return qk_f32 ? launch_from_k4p(src, dst, B, C, Tl, st) : from_act(src, dst, C, Tl); };
     if (r == LDS_OK && !a->plain_out) {
         if (a->v_split > 1) {
             // out = [B][Ck][To] plain q;k, then the raw VT buffer [B][(Cout-Ck)/D][ceil4(To)/4][D][4]
-            HIP_TRY(launch_from_k4p(kout, out, B, Ck, To, st));
+            HIP_TRY(from_out(kout, out, Ck, To));
             HIP_TRY(hipMemcpyAsync(out + (size_t)B * Ck * To, vout, sizeof(float) * B * (Cout - Ck) * To4, hipMemcpyDeviceToDevice, st));
         } else if (a->v_split) {
             // out = [q;k] back to plain (first 2/3 of the channels) followed by the already-plain v third
             float* tmpo = tmp.f((size_t)B * Ck * To);
             if (!tmpo) return fail(LDS_ENOMEM, "alloc");
-            HIP_TRY(launch_from_k4p(kout, tmpo, B, Ck, To, st));
+            HIP_TRY(from_out(kout, tmpo, Ck, To));
             for (int b = 0; b < B; ++b) {
                 HIP_TRY(hipMemcpyAsync(out + (size_t)b * Cout * To, tmpo + (size_t)b * Ck * To, sizeof(float) * Ck * To, hipMemcpyDeviceToDevice, st));
                 HIP_TRY(hipMemcpyAsync(out + (size_t)b * Cout * To + (size_t)Ck * To, vout + (size_t)b * (Cout - Ck) * To,
                                        sizeof(float) * (Cout - Ck) * To, hipMemcpyDeviceToDevice, st));
             }
         } else {
-            HIP_TRY(launch_from_k4p(kout, out, B, Ck, To, st));
+            HIP_TRY(from_out(kout, out, Ck, To));
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -1642,6 +1760,16 @@ extern "C" int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int i
     if (!a || !out || !ms_out || iters <= 0) return fail(LDS_EINVAL, "bad argument");
     int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream);
     if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_dma_last_config());
+    return r;
+}
+extern "C" int lds_test_dconv_bf3(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, void* stream) {
+    if (!a || !out) return fail(LDS_EINVAL, "bad argument");
+    return dconv_test_impl(a, out, lnpart, B, 0, nullptr, stream, 1, nprod);
+}
+extern "C" int lds_bench_dconv_bf3(const lds_dconv_test* a, float* out, int B, int iters, int nprod, float* ms_out, char* cfg_out, size_t cfg_cap, void* stream) {
+    if (!a || !out || !ms_out || iters <= 0) return fail(LDS_EINVAL, "bad argument");
+    int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream, 1, nprod);
+    if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_bf3_last_config());
     return r;
 }
 
@@ -1843,4 +1971,42 @@ extern "C" int lds_test_conv_transpose(const float* x, const float* w, const flo
     int r = run_conv(W, s, o, out, B, st);
     HIP_TRY(hipStreamSynchronize(st));
     return r;
+}
+
+extern "C" int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !out || (C & 7)) return fail(LDS_EINVAL, "bad argument");
+    TmpDev tmp;
+    float* k = tmp.f((size_t)B * k8b3_floats(C, T));
+    if (!k) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(launch_to_k8b3(x, k, B, C, T, C, 0, st));
+    HIP_TRY(launch_from_k8b3(k, out, B, C, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
+extern "C" int lds_test_gn_apply_bf3(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                                     const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    TmpDev tmp;
+    const int C = C1 + C2, nT = (T + 31) / 32;
+    float* g = up_vec(own, gamma, C);
+    float* be = up_vec(own, beta, C);
+    float* k1 = tmp.f((size_t)B * k8b3_floats(C1, T));
+    float* k2 = C2 ? tmp.f((size_t)B * k8b3_floats(C2, T)) : nullptr;
+    float* ky = tmp.f((size_t)B * k8b3_floats(C, T));
+    float* p1 = tmp.f((size_t)B * (C1 / 16) * nT * 2);
+    float* p2 = C2 ? tmp.f((size_t)B * (C2 / 16) * nT * 2) : nullptr;
+    if (!g || !be || !k1 || (C2 && (!k2 || !p2)) || !ky || !p1) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(launch_to_k8b3(x1, k1, B, C1, T, C1, 0, st));
+    HIP_TRY(launch_gn_partials_bf3(k1, C1, T, (float2*)p1, B, st));
+    if (C2) {
+        HIP_TRY(launch_to_k8b3(x2, k2, B, C2, T, C2, 0, st));
+        HIP_TRY(launch_gn_partials_bf3(k2, C2, T, (float2*)p2, B, st));
+    }
+    HIP_TRY(launch_gn_stream_bf3(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (const float2*)p1, (const float2*)p2, ky, B, st));
+    HIP_TRY(launch_from_k8b3(ky, out, B, C, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
 }

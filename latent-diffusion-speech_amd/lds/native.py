@@ -50,9 +50,12 @@ EXPORTS = [
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_gather_rows", "lds_resample_frames", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_lm_create", "lds_lm_destroy", "lds_lm_workspace_bytes", "lds_lm_encode",
-    "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_test_conv", "lds_test_dconv", "lds_bench_dconv",
-    "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p", "lds_test_ln_chain_k4p", "lds_test_attention_k4p",
-    "lds_test_conv_transpose", "lds_test_voc_step"]
+    "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_unet_set_gemm_mode", "lds_unet_get_gemm_mode"]
+# include/lds_test.h: single-op entry points for tests/ and tools/ (not part of the drop-in boundary)
+TEST_EXPORTS = [
+    "lds_test_conv", "lds_test_dconv", "lds_bench_dconv", "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p",
+    "lds_test_ln_chain_k4p", "lds_test_attention_k4p", "lds_test_conv_transpose", "lds_test_voc_step", "lds_test_dconv_bf3",
+    "lds_bench_dconv_bf3", "lds_test_k8b3_roundtrip", "lds_test_gn_apply_bf3"]
 
 
 def lib():
@@ -64,7 +67,7 @@ def lib():
                                "(there is no CPU fallback for the hot path)")
         L = C.CDLL(LIB_PATH)
         L.lds_last_error.restype = C.c_char_p
-        for n in EXPORTS:
+        for n in EXPORTS + TEST_EXPORTS:
             if n not in ("lds_last_error", "lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy", "lds_lm_destroy"):
                 getattr(L, n).restype = C.c_int
         for n in ("lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy", "lds_lm_destroy"):
