@@ -9,9 +9,17 @@ embedding -> 50-NFE DPM-Solver++(2M) sampling -> mel [B,512,80].
 
 Multi-GPU: the utterance batch shards across ranks (weak scaling: 16 utterances per GPU); the
 only collectives are the RCCL scatter of the inputs before the timed region and the gather of the
-mels inside it.  Prints ONE JSON line on rank 0.  At N = 1 the same line also carries `extra` legs
-(untimed for `value`): configs[3] end-to-end with the vocoder, the per-GPU share of configs[2]
-(UniPC, 20 NFE) and the B = 1 latency of the caller north_star names (22_infer_tts.py).
+results (mel; the waveform too for --workload e2e / full_tts) inside it.  Prints ONE JSON line on
+rank 0.  `python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset, N > 1) starts the N ranks
+itself -- a child `python -m torch.distributed.run ...` created before this process touches the GPU --
+checks that the line it gets back says n_gpus = N and exits non-zero otherwise: an N-GPU request can
+never silently measure one GPU.  --workload: sampler (configs[1] / [2]: the headline), e2e (configs[3]:
++ HiFi-VAEGAN decode, waveform gathered), full_tts (configs[4]: phones -> RoFormer generate -> codebook ->
+sampler -> vocoder, 8 utterances per GPU).  At N = 1 the sampler line also carries `extra` legs (untimed
+for `value`): configs[3] with the vocoder, the per-GPU share of configs[2] (UniPC, 20 NFE), the B = 1
+latency of the caller north_star names (22_infer_tts.py), and `split_bf16`: the same configs[1] step with
+every UNet GEMM on the fp32-equivalent split-bf16 path (csrc/conv_bf3.hip), reported next to -- never as --
+the exact-fp32 `value`.
 """
 import argparse
 import json
@@ -27,6 +35,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (same table); the split-bf16 path spends 6 bf16 products per fp32 product
+PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_TBS = 8.0               # HBM3E spec peak (same table; ~6.3 TB/s achievable)
 FRAME_SEC = 512 / 44100.0        # one mel frame = hop 512 @ 44.1 kHz (reference configs/config.yaml:3,12)
 UNET_GFLOP_PER_UTT_FWD = 40.98   # SURVEY.md 8d (T=512, M=80), algorithmic
@@ -52,22 +62,47 @@ def cpu_baseline(T, n_eval):
     solvers.dpm_solver_pp_2m(f, schedule.diffusion_buffers()["betas"], xT, n_eval)
     dt = time.perf_counter() - t0
     per_nfe = dt / n_eval
-    return {"value": T / (per_nfe * 50), "unit": "mel-frames/s", "cores": int(cores), "kind": "port",
+    # configs[0] (plumbing, CPU): 1 utterance x 256 frames, 100-step DDPM (k_step 100, infer_speedup 1) -- a bounded sample of
+    # `n0` ancestral steps (one denoiser evaluation + the posterior update each), scaled to the 100 of the configuration
+    T0, n0 = 256, max(2, n_eval // 2)
+    cond0 = init_weights.uniform("bench.cpu.cond0", (1, 256, T0), 1, -1, 1)
+    x0 = init_weights.uniform("bench.cpu.xT0", (1, 80, T0), 2, -1.7, 1.7)
+    noise0 = init_weights.uniform("bench.cpu.noise0", (n0, 1, 80, T0), 3, -1.7, 1.7)
+    f0 = o_u2m.make_eps_fn(w, cfg, blocks, cond0)
+    t0 = time.perf_counter()
+    solvers.ddpm(f0, schedule.diffusion_buffers(), x0, n0, noise0)
+    dt0 = time.perf_counter() - t0
+    config0 = {"workload": "configs[0]: 1 utterance x 256 frames, 100-step DDPM (CPU plumbing case)", "seconds_per_100_steps": 100.0 * dt0 / n0,
+               "mel_frames_per_sec": T0 / (100.0 * dt0 / n0), "sample": f"{n0} ancestral steps ({dt0:.1f} s) scaled to 100"}
+    return {"value": T / (per_nfe * 50), "unit": "mel-frames/s", "cores": int(cores), "kind": "port", "config0_ddpm100_T256": config0,
             "sample": f"numpy oracle, 1 utterance x {T} frames, {n_eval}-NFE DPM-Solver++ run ({dt:.1f} s) scaled to 50 NFE",
             "reference_torch_cpu_8core_survey": 29.0,
             "note": "the reference's own torch-CPU path measured during the survey (8 cores, BASELINE.md 4) is ~29 mel-frames/s; "
                     "this numpy port is ~7x slower than that and is a reported baseline only"}
 
 
+def _sha256(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def lib_fingerprint():
+    """what a counter summary must have been taken on to describe THIS run: the kernels' shared object"""
+    return _sha256(os.path.join(ROOT, "latent-diffusion-speech_amd", "lds", "liblds.so"))
+
+
 def _newest_profile_json(suffix):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1]))
+        return json.load(open(files[-1])), os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def _pmc_key(kernel_name):
@@ -80,24 +115,18 @@ def _pmc_key(kernel_name):
     return f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}, 1, false>" if nst else None
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/*_hbm_traffic.json, produced by
-    tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if there is none."""
-    d, key = _newest_profile_json("_hbm_traffic.json"), _pmc_key(kernel_name)
-    try:
-        return d["kernels"][key]["hbm_bytes_per_launch"] if d and key in d["kernels"] else None
-    except Exception:
-        return None
-
-
-def pmc_mfma_util(kernel_name):
-    """MFMA-busy fraction of `kernel_name` from the newest committed counter summary (profiles/*_mfma_util.json: separate
-    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES pass); None if there is none."""
-    d, key = _newest_profile_json("_mfma_util.json"), _pmc_key(kernel_name)
-    try:
-        return d["kernels"][key] if d and key in d["kernels"] else None
-    except Exception:
-        return None
+def pmc_lookup(kernel_name, suffix, field=None):
+    """(value, provenance) for `kernel_name` from the newest committed counter summary profiles/*<suffix> (separate rocprofv3 --pmc
+    passes summarised by tools/summarize_pmc.py / summarize_mfma.py).  These are NOT measured in this run: the provenance says which
+    file, which commit and which liblds.so it was taken on, and `stale` is true when that library is not the one loaded now."""
+    d, fname = _newest_profile_json(suffix)
+    key = _pmc_key(kernel_name)
+    if not d or key is None or key not in d.get("kernels", {}):
+        return None, None
+    v = d["kernels"][key]
+    prov = {"file": "profiles/" + fname, "commit": d.get("commit"), "lib_sha256": d.get("lib_sha256")}
+    prov["stale"] = (d.get("lib_sha256") is None) or (d.get("lib_sha256") != lib_fingerprint())
+    return (v[field] if field else v), prov
 
 
 class NativeProfiler:
@@ -132,14 +161,15 @@ def roofline_from_profile(prof):
     conv_tf, conv_ms = conv_family_rate(prof)
     roof = {
         "bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["name"]),
+        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_lookup(dom["name"], "_hbm_traffic.json", "hbm_bytes_per_launch")[0],
+        "traffic_source": pmc_lookup(dom["name"], "_hbm_traffic.json", "hbm_bytes_per_launch")[1],
         "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"],
         "launches": dom["count"], "avg_launch_us": 1e3 * dom["ms"] / dom["count"],
         "gflop_per_launch": dom["flops"] / dom["count"] / 1e9,
         "share_of_step_time": dom["ms"] / tot_ms,
         "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
         "all_conv_gemm_share": conv_ms / tot_ms,
-        "mfma_util_pmc": pmc_mfma_util(dom["name"]),
+        "mfma_util_pmc": pmc_lookup(dom["name"], "_mfma_util.json")[0], "mfma_util_source": pmc_lookup(dom["name"], "_mfma_util.json")[1],
         "launches_per_step": int(sum(r["count"] for r in prof)),
     }
     # the memory-bound families against the HBM roofline (algorithmic bytes / HIP-event time)
@@ -178,38 +208,104 @@ def timed_loop(step, steps, warmup, world, sync, dist=None, dev=None):
     return dt, out
 
 
-def run_job(args, rank, world, dev, model, voc=None, dist=None, sync=None, profiler=None, make_inputs=None, on_output=None):
+class SamplerPipeline:
+    """configs[1] / [2] (and, with a vocoder, configs[3]): units -> mel [-> wav].  inputs: units [n,T,1280] f32, spk [n,1] i64."""
+    name = "sampler"
+
+    def __init__(self, args, model, make_inputs, voc=None):
+        self.args, self.model, self.voc, self._make = args, model, voc, make_inputs
+        self.B, self.T = args.batch, args.frames
+        if voc is not None:
+            self.name = "e2e"
+
+    def input_specs(self, n):
+        return [((n, self.T, 1280), torch.float32), ((n, 1), torch.int64)]
+
+    def make_inputs(self, n):
+        return list(self._make(n, self.T))
+
+    def step(self, units, spk):
+        mel = self.model(units, None, spk_id=spk, infer=True, infer_speedup=1000 // self.args.nfe, method=self.args.method)
+        out = {"mel": mel}
+        if self.voc is not None:
+            out["wav"] = self.voc(mel)
+        return out
+
+    def check(self, outs, n):
+        assert bool(torch.isfinite(outs["mel"]).all()), "non-finite mel"
+        assert tuple(outs["mel"].shape) == (n, self.T, 80), tuple(outs["mel"].shape)
+        if "wav" in outs:
+            assert bool(torch.isfinite(outs["wav"]).all()), "non-finite waveform"
+            assert tuple(outs["wav"].shape)[0] == n, tuple(outs["wav"].shape)
+
+    def describe(self):
+        a = self.args
+        return (f"configs[1]: batch={self.B}x{self.T}-frame utterances per GPU, {a.nfe}-step {a.method}, unet1d denoiser, 80-ch mel"
+                + (" + HiFi-VAEGAN vocoder, waveform gathered (configs[3])" if self.voc is not None else ""))
+
+
+class FullTTSPipeline:
+    """configs[4] (reference 22_infer_tts.py:76-114): phones, tones -> RoFormer generate (T sampled semantic tokens) -> k-means codebook
+    rows -> Unit2Mel sampler -> HiFi-VAEGAN waveform.  inputs: phones, tones [n,Lp] i64, spk [n,1] i64."""
+    name = "full_tts"
+
+    def __init__(self, args, model, voc, text2semantic, codebook_lookup, Lp=64):
+        self.args, self.model, self.voc, self.t2s, self.lookup, self.Lp = args, model, voc, text2semantic, codebook_lookup, Lp
+        self.B, self.T = args.batch, args.frames
+
+    def input_specs(self, n):
+        return [((n, self.Lp), torch.int64), ((n, self.Lp), torch.int64), ((n, 1), torch.int64)]
+
+    def make_inputs(self, n):
+        idx = np.arange(n * self.Lp).reshape(n, self.Lp)
+        phones = torch.from_numpy((idx * 7 % 107 + 1).astype(np.int64))
+        tones = torch.from_numpy((idx * 5 % 12).astype(np.int64))
+        spk = torch.from_numpy((np.arange(n) * 37 % 323 + 1).astype(np.int64).reshape(n, 1))
+        return [phones, tones, spk]
+
+    def step(self, phones, tones, spk):
+        tok = self.t2s(phones, tones, self.T + 1)             # seeded random weights never emit EOS: exactly T tokens per row
+        assert tuple(tok.shape) == (phones.shape[0], self.T), tuple(tok.shape)
+        units = self.lookup(tok)
+        mel = self.model(units, None, spk_id=spk, infer=True, infer_speedup=1000 // self.args.nfe, method=self.args.method)
+        return {"mel": mel, "wav": self.voc(mel)}
+
+    check = SamplerPipeline.check
+
+    def describe(self):
+        a = self.args
+        return (f"configs[4]: batch={self.B} utterances per GPU, {self.Lp} phones -> RoFormer top-k sampling of {self.T} semantic tokens -> codebook -> "
+                f"{a.nfe}-step {a.method} -> HiFi-VAEGAN, waveform gathered")
+
+
+def run_job(args, rank, world, dev, model=None, voc=None, dist=None, sync=None, profiler=None, make_inputs=None, on_output=None, pipeline=None):
     """The bench proper, parameterised so tests can drive the multi-rank plumbing on CPU (gloo) with a stub model.
     Returns the result dict on rank 0 (None elsewhere)."""
     from lds import shard
-    B, T = args.batch, args.frames
-    speedup = 1000 // args.nfe
+    pipe = pipeline if pipeline is not None else SamplerPipeline(args, model, make_inputs, voc)
+    B, T = pipe.B, pipe.T
     sync = sync or (lambda: None)
 
     # synthetic inputs for the global batch live on rank 0 and are scattered over RCCL (untimed set-up)
-    if rank == 0:
-        units_all, spk_all = make_inputs(world * B, T)
-    else:
-        units_all = spk_all = torch.empty(0, device=dev)
     force = dist is not None      # (--rehearse-rccl: the collectives run even at N = 1)
-    units = shard.scatter_batch(units_all, rank, world, shape=(world * B, T, 1280), dtype=torch.float32, device=dev, force=force)
-    spk = shard.scatter_batch(spk_all, rank, world, shape=(world * B, 1), dtype=torch.int64, device=dev, force=force)
-    del units_all
+    full = [t.to(dev) for t in pipe.make_inputs(world * B)] if rank == 0 else None
+    local = []
+    for k, (shape, dtype) in enumerate(pipe.input_specs(world * B)):
+        src = full[k] if rank == 0 else torch.empty(0, device=dev)
+        local.append(shard.scatter_batch(src, rank, world, shape=shape, dtype=dtype, device=dev, force=force))
+    del full
 
     def step(gather=True):
-        mel = model(units, None, spk_id=spk, infer=True, infer_speedup=speedup, method=args.method)
-        wav = voc(mel) if voc is not None else None
-        out = shard.gather_batch(mel, rank, world, sizes=[B] * world, force=force) if gather else mel
-        return out, wav
+        outs = pipe.step(*local)
+        if gather:
+            outs = {k: shard.gather_batch(v, rank, world, sizes=[B] * world, force=force) for k, v in outs.items()}
+        return outs
 
-    dt, (out, wav) = timed_loop(step, args.steps, args.warmup, world, sync, dist, dev)
-    if out is not None:
-        assert bool(torch.isfinite(out).all()), "non-finite mel"
-        assert tuple(out.shape) == (world * B, T, 80), tuple(out.shape)
+    dt, outs = timed_loop(step, args.steps, args.warmup, world, sync, dist, dev)
+    if rank == 0:
+        pipe.check(outs, world * B)
         if on_output is not None:
-            on_output(out)
-    if wav is not None:
-        assert bool(torch.isfinite(wav).all()), "non-finite waveform"
+            on_output(outs["mel"])
 
     frames = world * B * T * args.steps
     value = frames / dt
@@ -217,9 +313,8 @@ def run_job(args, rank, world, dev, model, voc=None, dist=None, sync=None, profi
         "metric": "mel_frames_per_sec", "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: batch={B}x{T}-frame utterances per GPU, {args.nfe}-step {args.method}, unet1d denoiser, 80-ch mel"
-                               + (" + HiFi-VAEGAN vocoder (configs[3])" if voc is not None else ""),
-                   "utterances_per_gpu": B, "frames": T, "nfe": args.nfe, "method": args.method, "parallelism": f"batch-shard x{world}"},
+        "config": {"workload": pipe.describe(), "pipeline": pipe.name, "utterances_per_gpu": B, "frames": T, "nfe": args.nfe, "method": args.method,
+                   "parallelism": f"batch-shard x{world}", "gathered": sorted(outs.keys()) if rank == 0 else None},
         "x_realtime": value * FRAME_SEC, "rtf": 1.0 / (value * FRAME_SEC),
         "mel_frames_per_sec_per_gpu": value / world,
     }
@@ -233,6 +328,62 @@ def run_job(args, rank, world, dev, model, voc=None, dist=None, sync=None, profi
     return res
 
 
+def split_bf16_leg(args, model, make_inputs):
+    """configs[1] again with every convolution / linear layer of the UNet as an fp32-equivalent split-bf16 GEMM (csrc/conv_bf3.hip: three
+    bf16 terms per fp32 operand, six bf16 products per fp32 product, fp32 accumulate).  Same parity suite, same tolerances
+    (tests/test_gpu_model.py runs every whole-path test in both modes); error study: profiles/r03_split_bf16_probe.json.  Reported next
+    to the exact-fp32 `value`, never as it."""
+    unet = model.decoder.denoise_fn
+    units, spk = make_inputs(args.batch, args.frames)
+    sync = torch.cuda.synchronize
+    keep = {}
+
+    def step():
+        keep["mel"] = model(units, None, spk_id=spk, infer=True, infer_speedup=1000 // args.nfe, method=args.method)
+
+    def seeded(mode):                                           # one run with an injected x_T, so the two paths see the same start
+        unet.set_gemm_mode(mode)
+        real = torch.randn
+        xT = real((args.batch, 1, 80, args.frames), device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+        torch.randn = lambda *a, **k: xT.clone()
+        try:
+            step(); sync()
+        finally:
+            torch.randn = real
+        return keep["mel"].clone()
+    try:
+        y32, y16 = seeded("f32"), seeded("split_bf16")
+        rel = float((y16 - y32).abs().max() / y32.abs().max())
+        step(); sync()                                          # (mode is split_bf16 from here on)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt = (time.perf_counter() - t0) / args.steps
+        assert bool(torch.isfinite(keep["mel"]).all())
+        prof = NativeProfiler().run(step)
+        roof, breakdown = roofline_from_profile(prof)
+        dom = max((r for r in prof if r["name"].startswith("conv_bf3")), key=lambda r: r["ms"])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        conv_tf, _ = conv_family_rate(prof)
+        fps = args.batch * args.frames / dt
+        return {
+            "workload": f"configs[1] with split-bf16 GEMMs: batch={args.batch}x{args.frames} frames, {args.nfe}-step {args.method}",
+            "dtype": "f32-equivalent (3xbf16 operands, 6 products, f32 accumulate)",
+            "ms_per_step": 1e3 * dt, "mel_frames_per_sec": fps, "x_realtime": fps * FRAME_SEC,
+            "unet_algorithmic_tflops": UNET_GFLOP_PER_UTT_FWD * (args.frames / 512.0) * args.batch * args.nfe * 1e9 / dt / 1e12,
+            "max_rel_diff_vs_exact_f32_same_xT": rel,
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_SPLIT_BF16_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
+                         "frac": ach / PEAK_SPLIT_BF16_TFLOPS, "peak_note": "2.5 PFLOP/s dense bf16 / 6 bf16 products per fp32 product",
+                         "launches": dom["count"], "avg_launch_us": 1e3 * dom["ms"] / dom["count"], "gflop_per_launch": dom["flops"] / dom["count"] / 1e9,
+                         "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / PEAK_SPLIT_BF16_TFLOPS,
+                         "all_conv_gemm_vs_f32_mfma_peak": conv_tf / PEAK_F32_MFMA_TFLOPS, "launches_per_step": roof["launches_per_step"]},
+            "kernel_breakdown_ms": breakdown,
+        }
+    finally:
+        unet.set_gemm_mode("f32")
+
+
 def extra_legs(args, dev, model, make_inputs):
     """configs[3], configs[2]'s per-GPU share and the B = 1 latency (N = 1 only; none of them feeds `value`)."""
     from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
@@ -240,6 +391,7 @@ def extra_legs(args, dev, model, make_inputs):
     T = args.frames
     sync = torch.cuda.synchronize
     extra = {}
+    extra["split_bf16"] = split_bf16_leg(args, model, make_inputs)
     units, spk = make_inputs(args.batch, T)
 
     def timeit(fn, n):
@@ -321,6 +473,7 @@ def extra_legs(args, dev, model, make_inputs):
     keep = {}
 
     def lm_only():
+        torch.manual_seed(1234)                                                 # the sampler's uniforms: same draws every call
         keep["tok"] = infer_tts.text2semantic(lm, phones, tones, 1, T + 1)      # random weights never emit EOS: exactly T tokens
 
     def full():
@@ -341,6 +494,7 @@ def extra_legs(args, dev, model, make_inputs):
     p1, t1 = phones[:1].contiguous(), tones[:1].contiguous()
 
     def lm_one():
+        torch.manual_seed(1234)
         keep["tok1"] = infer_tts.text2semantic(lm, p1, t1, 1, T + 1)
 
     def full_one():
@@ -364,72 +518,155 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
+    ap.add_argument("--workload", choices=["sampler", "e2e", "full_tts"], default="sampler",
+                    help="sampler = configs[1]/[2] (headline); e2e = + vocoder, waveform gathered (configs[3]); full_tts = phones -> LM -> ... -> waveform (configs[4])")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 16; 8 for --workload full_tts: configs[4] is 64 on 8 GPUs)")
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--nfe", type=int, default=50)
     ap.add_argument("--method", default="dpm-solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nfe", type=int, default=8)
-    ap.add_argument("--vocoder", action="store_true", help="run the HiFi-VAEGAN decode inside the timed step (BASELINE config 4)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (configs[3], UniPC-20, B=1 latency) at N=1")
+    ap.add_argument("--vocoder", action="store_true", help="same as --workload e2e")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (split-bf16, configs[3], UniPC-20, B=1 latency, configs[4] share) at N=1")
     ap.add_argument("--rehearse-rccl", action="store_true",
                     help="N=1 only: open a single-rank RCCL process group and issue every collective of the N>1 path (scatter, gather, barrier, all-reduce)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented roofline step (for rocprofv3 --pmc passes)")
-    return ap.parse_args(argv)
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="tests only: gloo ranks on the CPU with stand-in models (exercises the launcher / scatter / gather / JSON plumbing without a GPU)")
+    args = ap.parse_args(argv)
+    if args.vocoder and args.workload == "sampler":
+        args.workload = "e2e"
+    if args.batch is None:
+        args.batch = 8 if args.workload == "full_tts" else 16
+    return args
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a child `python -m torch.distributed.run` (this process
+    has not touched the GPU and never will), pass their output through, and insist that the one JSON line says n_gpus = N."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run failed with exit code {proc.returncode}")
+    if line is None:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run printed no result line")
+    if json.loads(line).get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py: asked for --gpus {args.gpus} but the result line says n_gpus = {json.loads(line).get('n_gpus')}")
+    print(line, flush=True)
+    return 0
+
+
+class _StubUnit2Mel:
+    """--stub-cpu: mel[b,t,:] = 2 * units[b,t,:80] + spk_id[b] (per-utterance, so the gathered result identifies every shard)"""
+
+    def __call__(self, units, volume, spk_id=None, infer=True, infer_speedup=10, method="dpm-solver"):
+        return 2.0 * units[..., :80] + spk_id.to(torch.float32)[:, :, None]
+
+
+def build_pipeline(args, dev):
+    """models + the pipeline object of --workload (seeded random-init weights: no checkpoints exist)"""
+    from lds import init_weights
+
+    def make_inputs(n, T):
+        units = torch.from_numpy(init_weights.uniform("bench.units", (n, T, 1280), 1, -1.7, 1.7))
+        spk = torch.from_numpy((np.arange(n) * 37 % 323 + 1).astype(np.int64).reshape(n, 1))
+        return units.to(dev), spk.to(dev)
+
+    if args.stub_cpu:
+        model = _StubUnit2Mel()
+        voc = (lambda mel: mel.sum(-1, keepdim=True).transpose(1, 2).repeat(1, 1, 4)) if args.workload != "sampler" else None      # [n,1,4T]
+        if args.workload == "full_tts":
+            t2s = lambda ph, tn, max_length: (ph[:, :1] + torch.arange(max_length - 1)[None]) % 4096      # noqa: E731
+            lookup = lambda tok: tok.to(torch.float32)[..., None].repeat(1, 1, 1280) / 4096.0                # noqa: E731
+            return model, make_inputs, FullTTSPipeline(args, model, voc, t2s, lookup)
+        return model, make_inputs, SamplerPipeline(args, model, make_inputs, voc)
+
+    from diffusion.unit2mel import Unit2Mel
+    model = Unit2Mel(1280, 323, 80).to(dev).eval()           # build-owned seeded init, seed 0
+    voc = None
+    if args.workload != "sampler":
+        from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+        from lds import arch
+        h = arch.SYNTHETIC_VOCODER_H
+        voc = Hifi_VAEGAN(None, device=dev, h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
+    if args.workload == "full_tts":
+        sys.path.insert(0, ROOT)
+        import infer_tts
+        from lds import native
+        lm = infer_tts.synthetic_lm(dev)
+        codebook = torch.from_numpy(init_weights.uniform("synthetic.codebook", (4096, 1280), 5, -1.7, 1.7)).to(dev)
+
+        def t2s(phones, tones, max_length):
+            torch.manual_seed(1234)                           # the top-k sampler's uniforms: the same draws every step
+            return infer_tts.text2semantic(lm, phones, tones, 1, max_length)
+        return model, make_inputs, FullTTSPipeline(args, model, voc, t2s, lambda tok: native.gather_rows(codebook, tok.clamp(max=4095)))
+    return model, make_inputs, SamplerPipeline(args, model, make_inputs, voc)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args, argv)                       # before anything in this process touches the GPU
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:                                   # never fall back to fewer GPUs than asked for
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
         # This image's driver only supports dmabuf IPC; the run environment exports HSA_ENABLE_IPC_MODE_LEGACY=0 for
         # multi-process GPU work (without it RCCL fails with `hipIpcGetMemHandle: invalid argument`).  Keep the caller's value.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if args.stub_cpu:
+        dev = torch.device("cpu")
+        sync = None
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
     if world > 1 or args.rehearse_rccl:
         import torch.distributed as dist
         if world == 1:      # one-GPU rehearsal of the N > 1 branch: a single-rank RCCL group, every collective of the job still issued
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.stub_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from diffusion.unit2mel import Unit2Mel
-    from lds import init_weights
-
-    model = Unit2Mel(1280, 323, 80).to(dev).eval()           # build-owned seeded init, seed 0
-
-    def make_inputs(n, T):
-        units = torch.from_numpy(init_weights.uniform("bench.units", (n, T, 1280), 1, -1.7, 1.7)).to(dev)
-        spk = torch.from_numpy((np.arange(n) * 37 % 323 + 1).astype(np.int64).reshape(n, 1)).to(dev)
-        return units, spk
-
-    voc = None
-    if args.vocoder:
-        from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
-        from lds import arch
-        h = arch.SYNTHETIC_VOCODER_H
-        voc = Hifi_VAEGAN(None, device=dev, h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
-
-    res = run_job(args, rank, world, dev, model, voc=voc, dist=dist, sync=torch.cuda.synchronize,
-                  profiler=None if args.no_profile else NativeProfiler(), make_inputs=make_inputs)
+    model, make_inputs, pipe = build_pipeline(args, dev)
+    profiler = None if (args.no_profile or args.stub_cpu) else NativeProfiler()
+    res = run_job(args, rank, world, dev, dist=dist, sync=sync, profiler=profiler, pipeline=pipe)
     if rank == 0:
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not args.stub_cpu and args.workload == "sampler":
             res["extra"] = extra_legs(args, dev, model, make_inputs)
-        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not args.stub_cpu:      # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_nfe)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

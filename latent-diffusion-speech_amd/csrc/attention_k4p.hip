@@ -12,6 +12,7 @@
 // (finite) and their V entries are zeros (VT tail written by the producer, or the buffer range check), so 0 * V = 0.
 // Output is written in K4P (two 8-byte stores per 8-channel block, pad frames included).
 #include "k4p.h"
+#include "k8b3.h"
 #include "kernels.h"
 
 #include <hip/hip_ext.h>
@@ -72,7 +73,7 @@ static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc
 // staged tile, so twice as many waves share the work; the partial (max, sum, output) triples meet through LDS at the end.
 template <int D, int NW, int NST, int KS>
 __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ out,
-                                                                int C, int T, float scale2) {
+                                                                int C, int T, float scale2, int out_bf3) {
     using Cfg = AttCfg<D, NW, NST, KS>;
     constexpr int NWQ = NW / KS;
     constexpr int KB = Cfg::KB, DQ = Cfg::DQ, DT = Cfg::DT, KPW = Cfg::KPW, VPW = Cfg::VPW, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE;
@@ -228,7 +229,30 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // own + partner (each appears once)
     }
-    if (tq < T) {
+    if (tq < T && out_bf3) {
+        // K8B3 output (k8b3.h; the split-bf16 path's to_out projection reads it): rows 8g + 4h + e of a 32-row tile are channel
+        // positions 4h + e of 8-channel block g -- this lane half's 8 bytes of each plane's 16-byte entry
+        const float rl = 1.0f / l;
+        char* ob = reinterpret_cast<char*>(out);
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (i * 32 + 8 * g >= D) break;
+                const int q = (hd * D + i * 32) / 8 + g;
+                unsigned a1, a2, a3, b1, b2, b3;
+                k8_split_pair(o[i][4 * g] * rl, o[i][4 * g + 1] * rl, a1, a2, a3);
+                k8_split_pair(o[i][4 * g + 2] * rl, o[i][4 * g + 3] * rl, b1, b2, b3);
+                const unsigned pa[3] = {a1, a2, a3}, pb[3] = {b1, b2, b3};
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    char* e = ob + ((((long long)b * (C >> 3) + q) * 3 + pl) * Tp + tq + 1) * 16 + h * 8;
+                    k8_store_wt(e, k8_u32x2{pa[pl], pb[pl]});
+                    if (tq == 0) *reinterpret_cast<k8_u32x2*>(e - 16) = k8_u32x2{0u, 0u};
+                    if (tq == T - 1) *reinterpret_cast<k8_u32x2*>(e + 16) = k8_u32x2{0u, 0u};
+                }
+            }
+    } else if (tq < T) {
         const float rl = 1.0f / l;
         float* ob = out + (long long)b * C * Tp;
 #pragma unroll
@@ -249,7 +273,7 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 }
 
 template <int D, int NW, int NST, int KS>
-static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, hipStream_t s) {
+static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, int out_bf3, hipStream_t s) {
     using Cfg = AttCfg<D, NW, NST, KS>;
     auto kern = attention_k4p_kernel<D, NW, NST, KS>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
@@ -259,33 +283,39 @@ static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B
     }
     constexpr int QPB = NW / KS * 32;       // queries per workgroup
     hipEvent_t e0, e1;
-    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, e0, e1, 0, qk, vt, out, C, T, scale);
-    else hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale);
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, e0, e1, 0, qk, vt, out, C, T, scale, out_bf3);
+    else hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale, out_bf3);
     return hipGetLastError();
 }
 
 template <int D>
-static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
+static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, hipStream_t s) {
     const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
     constexpr int NST = (D == 64) ? 2 : 3;
     // judged at the nominal per-GPU batch (16): the choice fixes the summation order, which must not depend on the batch size
     const long long hb = (long long)heads * 16;
     // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
     // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
-    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1>(qk, vt, out, B, C, T, heads, scale, s);
-    if (T > 32) return launch_cfg<D, 4, NST, 2>(qk, vt, out, B, C, T, heads, scale, s);
-    return launch_cfg<D, 1, 2, 1>(qk, vt, out, B, C, T, heads, scale, s);
+    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    if (T > 32) return launch_cfg<D, 4, NST, 2>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    return launch_cfg<D, 1, 2, 1>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
 }
 
-hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
+static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, hipStream_t s) {
     if (C % heads) return hipErrorInvalidValue;
     ProfScope ps(s, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
     switch (C / heads) {
-        case 32: return launch_dk<32>(qk, vt, out, B, C, T, heads, s);
-        case 48: return launch_dk<48>(qk, vt, out, B, C, T, heads, s);
-        case 64: return launch_dk<64>(qk, vt, out, B, C, T, heads, s);
+        case 32: return launch_dk<32>(qk, vt, out, B, C, T, heads, out_bf3, s);
+        case 48: return launch_dk<48>(qk, vt, out, B, C, T, heads, out_bf3, s);
+        case 64: return launch_dk<64>(qk, vt, out, B, C, T, heads, out_bf3, s);
         default: return hipErrorInvalidValue;
     }
+}
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
+    return attention_any(qk, vt, out, B, C, T, heads, 0, s);
+}
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s) {
+    return attention_any(qk, vt, (float*)out, B, C, T, heads, 1, s);
 }
 
 }  // namespace lds

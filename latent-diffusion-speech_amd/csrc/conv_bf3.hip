@@ -614,23 +614,32 @@ static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
 static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst) {
     constexpr long long kNominalBatch = 16;
     auto blocks = [&](int bm_, int bn_) -> long long { return (a.Mp % bm_) ? -1 : (long long)(a.Mp / bm_) * ((a.To + bn_ - 1) / bn_) * kNominalBatch; };
-    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0);
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
         return;
     }
-    if (a.stride == 2 || a.ups) { bm = 64; bn = 64; bk = k32 ? 32 : 16; nst = 2; return; }
-    if (a.epi == EPI_GEGLU) { bm = 128; bn = (a.To > 64) ? 128 : 64; bk = k32 ? 32 : 16; nst = 2; return; }
-    const long long b64 = blocks(64, 64), b128 = blocks(128, 128);
-    if (a.KT == 3) {
-        if (b128 >= 512) { bm = 128; bn = 128; bk = 16; nst = 2; }
-        else if (b64 <= 256 && k32) { bm = 32; bn = 64; bk = 32; nst = 2; }
-        else { bm = 64; bn = 64; bk = k32 ? 32 : 16; nst = 2; }
+    // Rules from tools/split_bf16_probe.py (profiles/r03_split_bf16_probe.json).  The bf16 pipe eats operands 2.7x faster than the fp32
+    // one while a staged element is 6 bytes instead of 4, so what decides is bytes in flight per CU: stages of <= 80 KB (two
+    // co-resident workgroups) beat deeper K-steps everywhere, wide tiles (fewer bytes per MFMA) win as soon as they still fill the chip.
+    if (a.stride == 2 || a.ups) { bm = 64; bn = 64; bk = 16; nst = 3; return; }
+    if (a.epi == EPI_GEGLU) {
+        bm = 128;
+        if (a.To > 64) { bn = 128; bk = 16; nst = 3; }
+        else { bn = 64; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
         return;
     }
-    if (b128 >= 512) { bm = 128; bn = 128; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
-    else if (b64 <= 256 && k32) { bm = 32; bn = 64; bk = k64 ? 64 : 32; nst = 2; }
-    else { bm = 64; bn = 64; bk = k64 ? 64 : (k32 ? 32 : 16); nst = k64 ? 2 : 3; }
+    const long long b64 = blocks(64, 64);
+    if (a.KT == 3) {
+        if (b64 <= 256 && k32) { bm = 32; bn = 64; bk = 32; nst = 2; }
+        else if (blocks(64, 128) >= 256 && a.To >= 128) { bm = 64; bn = 128; bk = 16; nst = 2; }
+        else { bm = 64; bn = 64; bk = 16; nst = 3; }
+        return;
+    }
+    if (b64 <= 256 && k32) { bm = 32; bn = 64; bk = 32; nst = 2; }
+    else if (k32 && blocks(128, 64) >= 256) { bm = 128; bn = 64; bk = 32; nst = 2; }
+    else if (k32) { bm = 64; bn = 64; bk = 32; nst = 3; }
+    else { bm = 64; bn = 64; bk = 16; nst = 3; }
 }
 
 template <int BM, int BN, int BK3, int BK1, int NST>
@@ -652,7 +661,7 @@ static hipError_t launch_bf3_pair_cfg(const DmaConvArgs& a3, const DmaConvArgs& 
     return hipGetLastError();
 }
 
-// fused variant code for the pair, 0 = none: (BM << 16) | (BN << 8) | BK1
+// fused variant of the pair, 0 = none
 static int bf3_pair_variant(const DmaConvArgs& a3, const DmaConvArgs& a1) {
     auto plain = [](const DmaConvArgs& a) {
         return !a.voc && a.stride == 1 && !a.ups && a.epi == EPI_NONE && !a.ln_part && !a.out_f32 && a.Ci % 32 == 0 && a.C1 % 32 == 0 && a.Mp % 64 == 0 && a.B > 0 && a.To > 0;
@@ -663,17 +672,19 @@ static int bf3_pair_variant(const DmaConvArgs& a3, const DmaConvArgs& a1) {
     int bm, bn, bk, nst;
     bf3_pick(a3, 0, bm, bn, bk, nst);      // the k 3 half carries most of the work: its tile
     const bool k1_64 = (a1.Ci % 64 == 0) && (a1.C1 % 64 == 0);
-    if (bk != 32 || nst != 2 || bn != 64 || (bm != 32 && bm != 64)) return 0;
-    return (bm << 16) | (bn << 8) | (k1_64 ? 64 : 32);
+    (void)k1_64;
+    if (bm == 32 && bn == 64 && bk == 32 && nst == 2) return 1;
+    if (bm == 64 && bn == 128 && bk == 16 && nst == 2) return 2;
+    if (bm == 64 && bn == 64 && bk == 16 && nst == 3) return 3;
+    return 0;
 }
 bool conv_bf3_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1) { return bf3_pair_variant(a3, a1) != 0; }
 
 hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
-    switch (bf3_pair_variant(a3, a1)) {
-        case (32 << 16) | (64 << 8) | 64: return launch_bf3_pair_cfg<32, 64, 32, 64, 2>(a3, a1, s);
-        case (32 << 16) | (64 << 8) | 32: return launch_bf3_pair_cfg<32, 64, 32, 32, 2>(a3, a1, s);
-        case (64 << 16) | (64 << 8) | 64: return launch_bf3_pair_cfg<64, 64, 32, 64, 2>(a3, a1, s);
-        case (64 << 16) | (64 << 8) | 32: return launch_bf3_pair_cfg<64, 64, 32, 32, 2>(a3, a1, s);
+    switch (bf3_pair_variant(a3, a1)) {      // the 1x1 half runs BK 32 on the k 3 half's tile
+        case 1: return launch_bf3_pair_cfg<32, 64, 32, 32, 2>(a3, a1, s);
+        case 2: return launch_bf3_pair_cfg<64, 128, 16, 32, 2>(a3, a1, s);
+        case 3: return launch_bf3_pair_cfg<64, 64, 16, 32, 3>(a3, a1, s);
         default: return hipErrorNotSupported;
     }
 }

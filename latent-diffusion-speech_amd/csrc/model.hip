@@ -539,6 +539,58 @@ static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, cons
     return LDS_OK;
 }
 
+static int run_dconv_pair_bf3(const ConvW& W3, const void* h, const ConvW& W1, const void* x1, int C1, const void* x2, int C2, int T, const float* bias_pair,
+                              float2* gnpart_out, void* out, int B, hipStream_t st) {
+    DmaConvArgs a3, a1;
+    DOpt o3;
+    o3.pad = 1;
+    int rc = fill_dconv(W3, (const float*)h, W3.Ci, nullptr, 0, T, o3, (float*)out, B, a3);
+    if (rc != LDS_OK) return rc;
+    DOpt o1;
+    o1.gnpart_out = gnpart_out;
+    rc = fill_dconv(W1, (const float*)x1, C1, (const float*)x2, C2, T, o1, (float*)out, B, a1);
+    if (rc != LDS_OK) return rc;
+    if (!W3.w3 || !W1.w3) return fail(LDS_EINVAL, "split-bf16 weights were not packed for this layer");
+    a3.w = (const float*)W3.w3; a1.w = (const float*)W1.w3;
+    a3.x2 = nullptr; a1.x2 = (const float*)x2;
+    a3.bias = nullptr;
+    a1.bias = bias_pair;
+    const double flops = 2.0 * B * (double)a1.To * (double)W3.Co * ((double)W3.Ci * 3.0 + (double)W1.Ci);
+    const double bytes = 6.0 * ((double)B * (W3.Ci + W1.Ci) * T + (double)W3.Co * (3.0 * W3.Ci + W1.Ci) + (double)B * a1.Cout * a1.To);
+    if (!conv_bf3_pair_applies(a3, a1)) return 1;
+    hipError_t e;
+    {
+        ProfScope ps(st, "conv_bf3", flops, bytes, true);
+        e = launch_conv_bf3_pair(a3, a1, st);
+        if (ps.on) {
+            std::string cfgs(conv_bf3_last_config());
+            std::string nm = "conv_bf3<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
+                char sh[96];
+                snprintf(sh, sizeof(sh), " Ci%d+%d Co%d K3+1 To%d", W3.Ci, W1.Ci, W3.Co, a1.To);
+                nm += sh;
+            }
+            ps.rename(nm);
+        }
+    }
+    if (e != hipSuccess) return fail(LDS_EHIP, "conv_bf3 pair launch failed (%s): Co %d Ci %d+%d To %d", hipGetErrorString(e), W3.Co, W3.Ci, W1.Ci, a1.To);
+    return LDS_OK;
+}
+
+// The UNet's plan is the same in both GEMM modes; these pick the kernel family.  In LDS_GEMM_SPLIT_BF16 mode every activation buffer
+// holds a K8B3 tensor (k8b3.h) instead of a K4P one -- except q / k / v, which stay fp32 for the attention kernel.
+static int dconv_any(bool bf3, const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, hipStream_t st) {
+    return bf3 ? run_dconv_bf3(W, x1, C1, x2, C2, Tsrc, o, out, B, st) : run_dconv(W, x1, C1, x2, C2, Tsrc, o, out, B, st);
+}
+static hipError_t gn_any(bool bf3, const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma, const float* beta,
+                         const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s) {
+    return bf3 ? launch_gn_stream_bf3(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s)
+               : launch_gn_stream(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s);
+}
+static hipError_t to_act_any(bool bf3, const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
+    return bf3 ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s);
+}
+
 // ================================================================================================
 // UNet
 // ================================================================================================
@@ -892,6 +944,9 @@ struct UnetWs {
 static size_t k4(int C, int T) { return (size_t)C * (T + 2); }
 
 static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
+    // floats of one activation tensor: K4P = C * (T + 2); K8B3 (split-bf16 mode) = 1.5x that
+    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    auto k4 = [bf3](int C, int Tl) -> size_t { return bf3 ? k8b3_floats(C, Tl) : (size_t)C * (Tl + 2); };
     const int nb = u->cfg.n_blocks, L = u->cfg.n_layers;
     const int* boc = u->cfg.block_out_channels;
     w.e1 = A.f((size_t)B * u->temb);
@@ -965,55 +1020,59 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut.
     // GroupNorm(+scale/shift)+SiLU is materialised once per tensor by a streaming pass (gn_stream) so the convolutions stay
     // VALU-free; its statistics come from the partials the producers of x1 / x2 / h1 wrote in their epilogues.
-    HIP_TRY(launch_gn_stream(x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.gp(x1), x2 ? w.gp(x2) : nullptr, w.gno, B, st));
+    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    HIP_TRY(gn_any(bf3, x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.gp(x1), x2 ? w.gp(x2) : nullptr, w.gno, B, st));
     DOpt o1;
     o1.pad = 1; o1.gnpart_out = w.gp(w.h1);
-    LDS_TRY(run_dconv(r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
-    HIP_TRY(launch_gn_stream(w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr,
-                             w.gno, B, st));
+    LDS_TRY(dconv_any(bf3, r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
+    HIP_TRY(gn_any(bf3, w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr, w.gno, B, st));
     const float* res = x1;
     if (r.has_sc) {
         // the shortcut rides in conv2's launch (second reduction into the same accumulators; skip-concat on read: two source pointers)
-        const int rc = run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st);
+        const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st)
+                           : run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st);
         if (rc != 1) return rc;
         DOpt os;      // no fused variant for these shapes: two launches
-        LDS_TRY(run_dconv(r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));
+        LDS_TRY(dconv_any(bf3, r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));
         res = w.sc;
     }
     DOpt o2;
     o2.pad = 1; o2.res = res; o2.gnpart_out = w.gp(out);
-    return run_dconv(r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
+    return dconv_any(bf3, r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
 }
 
 static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st) {
     // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major (K4P).  Every conv that feeds a
     // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer (QKV / FF1) combines them per column and
     // applies the LayerNorm in its epilogue (weights pre-multiplied by gamma, pack_ln_fold).
+    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
     const int C = t.C;
-    HIP_TRY(launch_gn_stream(x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
+    HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
     DOpt op;
     op.lnpart_out = w.lnp;
-    LDS_TRY(run_dconv(t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
+    LDS_TRY(dconv_any(bf3, t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
         DOpt oq;
         oq.plain_from = 2 * C; oq.out2 = w.v; oq.vt_D = C / u->heads;      // q, k in K4P; v in attention's VT layout
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
-        LDS_TRY(run_dconv(t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
-        HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
+        oq.out_f32 = bf3 ? 1 : 0;                                          // (split-bf16 mode: q / k / v stay fp32 for the attention kernel)
+        LDS_TRY(dconv_any(bf3, t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
+        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st));
+        else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
         DOpt oo;
         oo.res = h; oo.lnpart_out = w.lnp;
-        LDS_TRY(run_dconv(t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
+        LDS_TRY(dconv_any(bf3, t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
         float* tmp = h; h = hn; hn = tmp;
     }
     DOpt of;
     of.epi = EPI_GEGLU;
     of.ln_part = w.lnp; of.ln_np = C / 32; of.ln_c1 = t.ff1_c1; of.ln_c2 = t.ff1_c2;
-    LDS_TRY(run_dconv(t.ff1, h, C, nullptr, 0, T, of, w.ff, B, st));
+    LDS_TRY(dconv_any(bf3, t.ff1, h, C, nullptr, 0, T, of, w.ff, B, st));
     DOpt o2;      // ff.net.2 + residual + proj_out + residual in one launch (load_tfm: ff2_out)
     o2.res = x; o2.gnpart_out = w.gp(out);
-    return run_dconv(t.ff2_out, w.ff, 4 * C, h, C, T, o2, out, B, st);
+    return dconv_any(bf3, t.ff2_out, w.ff, 4 * C, h, C, T, o2, out, B, st);
 }
 
 // uniform_t: every batch element shares t[0] (the samplers' case) -> the time-embedding path runs for one column and
@@ -1035,10 +1094,11 @@ static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_b
     // conv_in is linear in its input channels: the condition's contribution (and the bias) is the same for every evaluation of the run.
     // It is computed here once; an evaluation convolves the 80 sample channels only and adds it as the residual (1008 -> 240 reduction
     // terms per output of conv_in, every NFE).
-    HIP_TRY(launch_to_k4p(cond, w.ck, B, u->H, T, u->H, 0, st));
+    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    HIP_TRY(to_act_any(bf3, cond, w.ck, B, u->H, T, u->H, 0, st));
     DOpt o;
     o.pad = 1;
-    return run_dconv(u->conv_in_c, w.ck, u->H, nullptr, 0, T, o, w.cinc, B, st);
+    return dconv_any(bf3, u->conv_in_c, w.ck, u->H, nullptr, 0, T, o, w.cinc, B, st);
 }
 
 // tproj_pre: this timestep's column of all resnets' time_emb_proj outputs, computed ahead by the sampler (implies uniform_t);
@@ -1051,6 +1111,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
     const int nb = u->cfg.n_blocks;
+    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
     // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch.
     // e1 = SiLU(linear_1(sinusoid(t))); emb = SiLU(linear_2(e1)) -- every consumer of emb applies SiLU first
     // (resnet.py:610), so only the activated embedding is stored
@@ -1065,16 +1126,16 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     const int cin = u->M + u->H;
     size_t si = 0;
     if (cond_staged) {      // sampler run: conv_in over the sample's channels + the condition half staged by unet_stage_cond
-        HIP_TRY(launch_to_k4p(x, w.xk, B, u->M, T, u->M, 0, st));
+        HIP_TRY(to_act_any(bf3, x, w.xk, B, u->M, T, u->M, 0, st));
         DOpt o;
         o.pad = 1; o.res = w.cinc; o.gnpart_out = w.gp(w.skips[si]);
-        LDS_TRY(run_dconv(u->conv_in_x, w.xk, u->M, nullptr, 0, T, o, w.skips[si], B, st));
+        LDS_TRY(dconv_any(bf3, u->conv_in_x, w.xk, u->M, nullptr, 0, T, o, w.skips[si], B, st));
     } else {
-        HIP_TRY(launch_to_k4p(x, w.xin, B, u->M, T, cin, 0, st));
-        HIP_TRY(launch_to_k4p(cond, w.xin, B, u->H, T, cin, u->M, st));
+        HIP_TRY(to_act_any(bf3, x, w.xin, B, u->M, T, cin, 0, st));
+        HIP_TRY(to_act_any(bf3, cond, w.xin, B, u->H, T, cin, u->M, st));
         DOpt o;
         o.pad = 1; o.gnpart_out = w.gp(w.skips[si]);
-        LDS_TRY(run_dconv(u->conv_in, w.xin, cin, nullptr, 0, T, o, w.skips[si], B, st));
+        LDS_TRY(dconv_any(bf3, u->conv_in, w.xin, cin, nullptr, 0, T, o, w.skips[si], B, st));
     }
     const float* cur = w.skips[si++];
     int Tl = T;
@@ -1093,7 +1154,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
         if (d.has_down) {
             DOpt o;
             o.pad = 1; o.stride = 2; o.gnpart_out = w.gp(w.skips[si]);
-            LDS_TRY(run_dconv(d.down, cur, d.ch, nullptr, 0, Tl, o, w.skips[si], B, st));
+            LDS_TRY(dconv_any(bf3, d.down, cur, d.ch, nullptr, 0, Tl, o, w.skips[si], B, st));
             Tl = down_len(Tl);
             cur = w.skips[si++];
             skipT.push_back(Tl);
@@ -1126,10 +1187,10 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             o.pad = 1; o.gnpart_out = w.gp(dst);
             if (Tn == 2 * Tl) {
                 o.ups = 1;
-                LDS_TRY(run_dconv(b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
+                LDS_TRY(dconv_any(bf3, b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
             } else {
-                HIP_TRY(launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st));
-                LDS_TRY(run_dconv(b.up, w.upt, b.ch, nullptr, 0, Tn, o, dst, B, st));
+                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st));
+                LDS_TRY(dconv_any(bf3, b.up, w.upt, b.ch, nullptr, 0, Tn, o, dst, B, st));
             }
             Tl = Tn;
             cur = dst;
@@ -1138,10 +1199,10 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     }
     // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031); eps leaves in the caller's frame-major layout
     const int c0 = u->cfg.block_out_channels[0];
-    HIP_TRY(launch_gn_stream(cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.gp(cur), nullptr, w.gno, B, st));
+    HIP_TRY(gn_any(bf3, cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.gp(cur), nullptr, w.gno, B, st));
     DOpt o;
     o.pad = 1; o.out_plain = 1;
-    return run_dconv(u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st);
+    return dconv_any(bf3, u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st);
 }
 
 extern "C" int lds_unet_forward(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,

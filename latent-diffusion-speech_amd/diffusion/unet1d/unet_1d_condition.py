@@ -36,6 +36,7 @@ class UNet1DConditionModel(ParamTree):
         self.cfg = cfg
         self.in_channels, self.out_channels = in_channels, out_channels
         self._native = None
+        self._gemm_mode = "f32"
 
     # Any change of the parameters drops the packed copy: .to()/.float() go through _apply; load_state_dict -- called on
     # this module OR on any parent (Unit2Mel / GaussianDiffusion: nn.Module.load_state_dict recurses through the children's
@@ -51,7 +52,18 @@ class UNet1DConditionModel(ParamTree):
     def native(self):
         if self._native is None:
             self._native = native.UNet(self.cfg, {k: v for k, v in self.state_dict().items()})
+            if self._gemm_mode != "f32":
+                self._native.set_gemm_mode(self._gemm_mode)
         return self._native
+
+    def set_gemm_mode(self, mode):
+        """"f32" (default): every conv / linear on the exact-fp32 MFMA.  "split_bf16": the same layers as fp32-equivalent split-bf16
+        GEMMs (three bf16 terms per operand, six products, fp32 accumulate; csrc/conv_bf3.hip) -- not part of the reference's API."""
+        if mode not in ("f32", "split_bf16"):
+            raise ValueError(mode)
+        self._gemm_mode = mode
+        if self._native is not None:
+            self._native.set_gemm_mode(mode)
 
     def forward(self, sample, timestep, **kwargs):
         """sample [B, M+H, T] (x stacked on cond, reference diffusion.py:105), timestep [B] or scalar."""

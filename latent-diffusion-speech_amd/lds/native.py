@@ -73,6 +73,8 @@ def lib():
         for n in ("lds_unet_destroy", "lds_embed_destroy", "lds_vocoder_destroy", "lds_lm_destroy"):
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_void_p]
+        L.lds_unet_set_gemm_mode.argtypes = [C.c_void_p, C.c_int]
+        L.lds_unet_get_gemm_mode.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -147,6 +149,14 @@ class UNet:
         if getattr(self, "h", None) and _lib is not None:
             _lib.lds_unet_destroy(self.h)
             self.h = None
+
+    def set_gemm_mode(self, mode):
+        """0 / "f32": exact-fp32 MFMA (default); 1 / "split_bf16": fp32-equivalent split-bf16 GEMMs (include/lds.h)"""
+        m = {"f32": 0, "split_bf16": 1}.get(mode, mode)
+        check(lib().lds_unet_set_gemm_mode(self.h, int(m)))
+
+    def gemm_mode(self):
+        return int(lib().lds_unet_get_gemm_mode(self.h))
 
     def forward(self, x, cond, t):
         import torch

@@ -31,3 +31,37 @@ def unet_weights():
     from lds import arch, init_weights
     cfg = arch.unet_config()
     return cfg, arch.unet_blocks(cfg), init_weights.init_state(arch.unet_param_shapes(cfg), 0)
+
+
+# ---- measured parity margins ------------------------------------------------------------------------------------------------
+# Every parity test reports (measured relative error, tolerance) through `margin`; at the end of the session the table is written to
+# gpurun_out/parity_margins.json (merged with what an earlier session left there) so that a GPU run leaves a record of HOW FAR inside
+# the tolerance each comparison sits, not only that it passed.  profiles/rNN_parity_margins.json is a committed copy of one such run.
+_MARGINS = {}
+
+
+def margin(name, measured, tol):
+    """record and assert: measured < tol"""
+    _MARGINS[name] = {"relmax": float(measured), "tol": float(tol), "frac_of_tol": float(measured) / float(tol)}
+    assert measured < tol, (name, measured, tol)
+
+
+@pytest.fixture
+def record_margin(request):
+    def rec(measured, tol, tag=""):
+        margin(request.node.name + (":" + tag if tag else ""), measured, tol)
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out", "parity_margins.json")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        old = json.load(open(out)) if os.path.exists(out) else {}
+        old.update(_MARGINS)
+        json.dump(dict(sorted(old.items())), open(out, "w"), indent=1)
+    except OSError:
+        pass

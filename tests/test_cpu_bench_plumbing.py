@@ -79,3 +79,36 @@ def test_bench_run_job_multi_rank_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("workload", ["sampler", "e2e", "full_tts"])
+def test_bench_main_spawns_its_own_ranks(workload):
+    """`python bench.py --gpus 2` with NO launcher around it: the parent starts the two ranks itself (a child
+    torch.distributed.run; --stub-cpu = gloo ranks with stand-in models), prints exactly one result line, and that line says n_gpus 2,
+    names the workload and, for the workloads with a vocoder, shows the waveform was gathered too."""
+    p, res = _run_bench(["--gpus", "2", "--stub-cpu", "--steps", "2", "--warmup", "1", "--batch", "3", "--frames", "8", "--workload", workload])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["config"]["pipeline"] == workload and res["config"]["utterances_per_gpu"] == 3
+    assert res["config"]["gathered"] == (["mel"] if workload == "sampler" else ["mel", "wav"])
+    assert abs(res["value"] - 2 * 3 * 8 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+
+
+def test_bench_main_refuses_a_world_size_mismatch():
+    """a launcher that provides fewer ranks than --gpus asks for must fail loudly, not measure one GPU and label it N"""
+    p, res = _run_bench(["--gpus", "2", "--stub-cpu", "--steps", "1", "--warmup", "0", "--batch", "2", "--frames", "8"],
+                        env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and res is None
+    assert "--gpus 2 but WORLD_SIZE=1" in p.stderr

@@ -14,14 +14,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_single_rank_rccl_group():
+@pytest.mark.parametrize("workload,batch,frames", [("sampler", 3, 64), ("e2e", 2, 32), ("full_tts", 2, 16)])
+def test_bench_single_rank_rccl_group(workload, batch, frames):
+    """every workload of bench.py through the RCCL branch: sampler (configs[1] / [2]), e2e (configs[3]: the waveform is gathered too),
+    full_tts (configs[4]: phones / tones scattered as int64, mel and waveform gathered)"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-rccl", "--steps", "1", "--warmup", "1", "--nfe", "2", "--batch", "3",
-                        "--frames", "64", "--no-extras", "--no-cpu-baseline", "--no-profile"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-rccl", "--workload", workload, "--steps", "1", "--warmup", "1", "--nfe", "2",
+                        "--batch", str(batch), "--frames", str(frames), "--no-extras", "--no-cpu-baseline", "--no-profile"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["metric"] == "mel_frames_per_sec" and line["value"] > 0
-    assert line["config"]["utterances_per_gpu"] == 3 and line["config"]["frames"] == 64
+    assert line["config"]["utterances_per_gpu"] == batch and line["config"]["frames"] == frames and line["config"]["pipeline"] == workload
+    assert line["config"]["gathered"] == (["mel"] if workload == "sampler" else ["mel", "wav"])
