@@ -614,7 +614,7 @@ static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
 static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst) {
     constexpr long long kNominalBatch = 16;
     auto blocks = [&](int bm_, int bn_) -> long long { return (a.Mp % bm_) ? -1 : (long long)(a.Mp / bm_) * ((a.To + bn_ - 1) / bn_) * kNominalBatch; };
-    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0);
+    const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
         return;
@@ -630,14 +630,17 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
         return;
     }
     const long long b64 = blocks(64, 64);
+    // fewer 64 x 64 tiles than CUs, or 1.5 per CU (conv_dma.hip dma_pick): 32 x 64 tiles with the K-step's groups split over the wave pairs
+    const bool small = k32 && (b64 <= 256 || (b64 < 512 && b64 % 256));
     if (a.KT == 3) {
-        if (b64 <= 256 && k32) { bm = 32; bn = 64; bk = 32; nst = 2; }
+        if (small) { bm = 32; bn = 64; bk = 32; nst = 2; }
         else if (blocks(64, 128) >= 256 && a.To >= 128) { bm = 64; bn = 128; bk = 16; nst = 2; }
         else { bm = 64; bn = 64; bk = 16; nst = 3; }
         return;
     }
-    if (b64 <= 256 && k32) { bm = 32; bn = 64; bk = 32; nst = 2; }
-    else if (k32 && blocks(128, 64) >= 256) { bm = 128; bn = 64; bk = 32; nst = 2; }
+    // (in the model, where operands arrive cold, the split tiles are bound by the number of sequential DMA round trips: the deepest K-step)
+    if (small) { bm = 32; bn = 64; bk = k64 ? 64 : 32; nst = 2; }
+    else if (k32 && blocks(128, 64) >= 512) { bm = 128; bn = 64; bk = 32; nst = 2; }
     else if (k32) { bm = 64; bn = 64; bk = 32; nst = 3; }
     else { bm = 64; bn = 64; bk = 16; nst = 3; }
 }
