@@ -160,17 +160,21 @@ int lds_lm_create(const lds_lm_cfg* cfg, int n_tensors, const char* const* names
                   lds_lm** out);
 void lds_lm_destroy(lds_lm* lm);
 int lds_lm_workspace_bytes(const lds_lm* lm, int B, int L, int max_length, size_t* out);
-/* phone, tone, spk_id: dev int64 [B,L] (spk_id may be NULL) -> enc dev [B,L,hidden] = encoder_hidden_states (roformer.py:196-204) */
-int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, float* enc, void* ws, size_t ws_bytes,
-                  int B, int L, void* stream);
+/* phone, tone, spk_id: dev int64 [B,L] (spk_id may be NULL) -> enc dev [B,L,hidden] = encoder_hidden_states (roformer.py:196-204).
+ * enc_len: dev int32 [B] or NULL -- the padding mask of a right-padded batch (reference roformer.py:182,209-214: attention_mask), given as
+ * the number of real positions per row: keys at positions >= enc_len[b] get probability 0 in every encoder self-attention. */
+int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, const int32_t* enc_len, float* enc, void* ws,
+                  size_t ws_bytes, int B, int L, void* stream);
 /* Roformer.generate (roformer.py:179-240): greedy (do_sample 0) or RepetitionPenalty -> Temperature -> TopK -> TopP -> one draw per
- * step.  uniforms dev [max_length-1][B]: the draw is the inverse-CDF rule over the vocabulary order with these numbers (torch's own
+ * step.  enc_len as above (roformer.py:229-236: encoder_attention_mask on the decoder's cross-attention) or NULL.  top_k: 1 .. 64, exactly
+ * k candidates survive (ties towards the lower id; HF also keeps logits tied with the k-th and accepts 0 / None = no filter -- not built).
+ * uniforms dev [max_length-1][B]: the draw is the inverse-CDF rule over the vocabulary order with these numbers (torch's own
  * multinomial stream cannot be reproduced outside torch).  tokens dev int64 [B][max_length] (BOS first; finished sequences padded);
  * logits_out optional dev [max_length-1][B][sem_vocab]; *n_tokens_host = length of the returned sequences incl. BOS.  The call
  * synchronises the stream every 8 steps to poll for EOS. */
-int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int max_length, int do_sample, int top_k, float top_p, float temperature,
-                    float repetition_penalty, const float* uniforms, int64_t* tokens, float* logits_out, int* n_tokens_host, void* ws,
-                    size_t ws_bytes, void* stream);
+int lds_lm_generate(lds_lm* lm, const float* enc, const int32_t* enc_len, int B, int L, int max_length, int do_sample, int top_k, float top_p,
+                    float temperature, float repetition_penalty, const float* uniforms, int64_t* tokens, float* logits_out, int* n_tokens_host,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* ---- per-launch HIP-event timing for bench.py's roofline leg (off by default) ------------------
  * lds_prof_enable(1) clears and starts recording one event pair per kernel launch on the launch

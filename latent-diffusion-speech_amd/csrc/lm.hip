@@ -296,14 +296,18 @@ __global__ void __launch_bounds__(256) lm_kv_pack_kernel(const float* __restrict
 //      64-key blocks; inside a wave, phase 1 has one key per lane (scores), phase 2 one output channel per lane with the two half-waves on
 //      alternate keys; the waves' (max, sum, partial output) meet through LDS in a fixed order.  d <= 32. ----
 __global__ void __launch_bounds__(256) lm_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kc, const float* __restrict__ vc, int cap,
-                                                      int Lq, int Lk, int H, int heads, float* __restrict__ out) {
+                                                      int Lq, int Lk_all, const int* __restrict__ klen, int H, int heads, float* __restrict__ out) {
     extern __shared__ float sc[];                      // [Lk rounded to 64] scores, then 4 x (max, sum, acc[32])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x;                       // (b, l, head)
-    const int d = H / heads, Lkp = (Lk + 63) & ~63;
+    const int d = H / heads, Lkp = (Lk_all + 63) & ~63;
     const int hd = item % heads;
     const long long n = item / heads;                  // token index b * Lq + l
     const int b = (int)(n / Lq);
+    // padding mask (reference roformer.py:209-236: attention_mask on the encoder's keys, encoder_attention_mask on the cross-attention's):
+    // right-padded rows, so the mask of batch row b is "keys [0, klen[b])"; masked keys get probability exactly 0 as with HF's -inf bias
+    const int kl = klen ? klen[b] : Lk_all;
+    const int Lk = (kl < Lk_all) ? (kl < 1 ? 1 : kl) : Lk_all;
     float* mrg = sc + Lkp;
     float qr[32];
 #pragma unroll
@@ -663,10 +667,11 @@ void lm_plan(const lds_lm* lm, LmArena& A, int B, int L, int cap, LmWs& w) {
         w.ckc.push_back(A.f((size_t)B * H * L)); w.cvc.push_back(A.f((size_t)B * H * L));
     }
 }
-hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* vc, int cap, int B, int Lq, int Lk, const lds_lm_cfg& c, float* out, hipStream_t st) {
+hipError_t lm_attention(const float* q, int ldq, const float* kc, const float* vc, int cap, int B, int Lq, int Lk, const int* klen, const lds_lm_cfg& c, float* out,
+                        hipStream_t st) {
     const int total = B * Lq * c.heads;
     const size_t lds = (size_t)(((Lk + 63) & ~63) + 4 * 34) * sizeof(float);
-    hipLaunchKernelGGL(lm_attn_kernel, dim3(total), dim3(256), lds, st, q, ldq, kc, vc, cap, Lq, Lk, c.hidden, c.heads, out);
+    hipLaunchKernelGGL(lm_attn_kernel, dim3(total), dim3(256), lds, st, q, ldq, kc, vc, cap, Lq, Lk, klen, c.hidden, c.heads, out);
     return hipGetLastError();
 }
 // rows [N][hidden] together with the LayerNorm that is still owed to them (ln == nullptr: already normalised)
@@ -691,8 +696,9 @@ hipError_t lm_dln(const LmLinear& W, const LmRows& X, int ldx, const LmRows* R, 
 // one BERT-style post-LN layer over N = B * L rows; self-attention over [pos0, pos0 + L) appended to the cache (kc, vc).
 // Every LayerNorm is deferred to the readers of its rows (lm_linear_dln_kernel): `x` comes in, and goes out, as rows + owed LayerNorm.
 // The three row buffers of the workspace rotate: input -> a (attention block) -> c (cross-attention block) -> output in the input's buffer.
+// self_klen / cross_klen: per-batch-row key counts of the padding mask (device int32 [B]) or null
 int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& w, LmRows& x, int B, int L, int pos0, float* kc, float* vc, int cap,
-             const float* ckc, const float* cvc, int Lenc, hipStream_t st) {
+             const float* ckc, const float* cvc, int Lenc, const int* self_klen, const int* cross_klen, hipStream_t st) {
     const lds_lm_cfg& c = lm->cfg;
     const int H = c.hidden, N = B * L;
     if (Ly.self.o.M != H || Ly.ff2.M != H || (Ly.has_cross && (Ly.cross.o.M != H || Ly.cross.q.K != H))) return lm_fail(LDS_EINVAL, "layer shapes");
@@ -703,13 +709,13 @@ int lm_layer(const lds_lm* lm, const LmStack& s, const LmLayer& Ly, const LmWs& 
         const LmRope rope{s.table, kc, vc, pos0, L, c.heads, cap};      // rotary embedding and cache append in the projection's epilogue
         LM_HIP(lm_dln<4>(Ly.self.qkv, x, H, nullptr, c.eps, w.qkv, 3 * H, N, st, &rope));
     }
-    LM_HIP(lm_attention(w.qkv, 3 * H, kc, vc, cap, B, L, pos0 + L, c, w.ctx, st));
+    LM_HIP(lm_attention(w.qkv, 3 * H, kc, vc, cap, B, L, pos0 + L, self_klen, c, w.ctx, st));
     const LmRows ctx{w.ctx, nullptr};
     LM_HIP(lm_dln<5>(Ly.self.o, ctx, H, &x, c.eps, free1, H, N, st));               // a = W_o ctx + LN(x)
     LmRows cur{free1, &Ly.self.ln};
     if (Ly.has_cross) {
         LM_HIP(lm_dln<0>(Ly.cross.q, cur, H, nullptr, c.eps, w.qkv, H, N, st));
-        LM_HIP(lm_attention(w.qkv, H, ckc, cvc, Lenc, B, L, Lenc, c, w.ctx, st));
+        LM_HIP(lm_attention(w.qkv, H, ckc, cvc, Lenc, B, L, Lenc, cross_klen, c, w.ctx, st));
         LM_HIP(lm_dln<5>(Ly.cross.o, ctx, H, &cur, c.eps, free2, H, N, st));        // c = W_o' ctx' + LN(a)
         cur = LmRows{free2, &Ly.cross.ln};
     }
@@ -730,9 +736,9 @@ extern "C" int lds_lm_workspace_bytes(const lds_lm* lm, int B, int L, int max_le
     return LDS_OK;
 }
 
-// phone, tone [B,L] int64 (dev), spk_id [B,L] int64 or NULL -> enc [B,L,hidden] (dev)
-extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, float* enc, void* ws, size_t ws_bytes, int B,
-                             int L, void* stream) {
+// phone, tone [B,L] int64 (dev), spk_id [B,L] int64 or NULL, enc_len [B] int32 (dev) or NULL = the padding mask's key counts -> enc [B,L,hidden] (dev)
+extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, const int32_t* enc_len, float* enc, void* ws,
+                             size_t ws_bytes, int B, int L, void* stream) {
     if (!lm || !phone || !tone || !enc || !ws || B <= 0 || L <= 0) return lm_fail(LDS_EINVAL, "bad argument");
     const lds_lm_cfg& c = lm->cfg;
     if (L > c.max_pos) return lm_fail(LDS_EINVAL, "sequence longer than max_position_embeddings");
@@ -748,7 +754,7 @@ extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* to
     LmRows cx{w.x, nullptr};
     for (const LmLayer& Ly : lm->enc.layers) {
         // the encoder's "cache" is just this layer's keys / values for all L positions
-        int r = lm_layer(lm, lm->enc, Ly, w, cx, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, st);
+        int r = lm_layer(lm, lm->enc, Ly, w, cx, B, L, 0, w.kc_tmp, w.vc_tmp, L, nullptr, nullptr, 0, enc_len, nullptr, st);
         if (r != LDS_OK) return r;
     }
     if (cx.ln) {      // the states leave the library normalised
@@ -762,14 +768,17 @@ extern "C" int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* to
 
 // enc [B,L,hidden] (dev); uniforms [max_length-1][B] (dev, sampling only); tokens [B][max_length] int64 (dev): BOS then the generated ids,
 // positions past the returned length are unspecified; logits_out optional [max_length-1][B][vocab] (dev).  *n_tokens_host = sequence length incl. BOS.
-extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int max_length, int do_sample, int top_k, float top_p, float temperature,
-                               float repetition_penalty, const float* uniforms, int64_t* tokens, float* logits_out, int* n_tokens_host, void* ws,
-                               size_t ws_bytes, void* stream) {
+extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, const int32_t* enc_len, int B, int L, int max_length, int do_sample, int top_k, float top_p,
+                               float temperature, float repetition_penalty, const float* uniforms, int64_t* tokens, float* logits_out, int* n_tokens_host,
+                               void* ws, size_t ws_bytes, void* stream) {
     if (!lm || !enc || !tokens || !n_tokens_host || !ws || B <= 0 || L <= 0 || max_length < 2) return lm_fail(LDS_EINVAL, "bad argument");
     const lds_lm_cfg& c = lm->cfg;
     if (do_sample && (!uniforms || top_k < 1 || top_k > kMaxTopK || top_k > c.sem_vocab || !(top_p > 0.f) || !(temperature > 0.f)))
         return lm_fail(LDS_EINVAL, "sampling needs uniforms, 1 <= top_k <= %d, top_p > 0, temperature > 0", kMaxTopK);
     if (max_length > c.max_pos) return lm_fail(LDS_EINVAL, "max_length exceeds max_position_embeddings");
+    // the encoder states come from lds_lm_encode (L <= max_pos); the cross-attention stages one score per encoder position in LDS
+    if (L < 1 || L > c.max_pos || (size_t)(((L + 63) & ~63) + 4 * 34) * sizeof(float) > 64 * 1024)
+        return lm_fail(LDS_EINVAL, "encoder length %d out of range (1 .. min(max_position_embeddings = %d, 16000))", L, c.max_pos);
     hipStream_t st = (hipStream_t)stream;
     LmArena A(ws, ws_bytes);
     LmWs w;
@@ -809,7 +818,7 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, int B, int L, int m
         }
         LmRows cx{w.x, nullptr};
         for (int i = 0; i < c.dec_layers; ++i) {
-            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, cx, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, st);
+            int r = lm_layer(lm, lm->dec, lm->dec.layers[i], w, cx, B, 1, step, w.kc[i], w.vc[i], max_length, w.ckc[i], w.cvc[i], L, nullptr, enc_len, st);
             if (r != LDS_OK) return r;
         }
         // LM head: h = GELU(W_t LN(x)) stored un-normalised, logits = W_d LN(h)

@@ -123,6 +123,19 @@ hipError_t launch_fill(float* p, float v, long long n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// dst[i] = v.f[i], i < n <= 64: a short host list travels in the launch's kernel arguments (no pageable host-to-device copy, whose
+// staging would block the calling thread and read host memory after the call returned)
+__global__ void __launch_bounds__(64) set_list_kernel(float* __restrict__ dst, FloatList64 v, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.f[threadIdx.x];
+}
+hipError_t launch_set_list(float* dst, const float* host, int n, hipStream_t s) {
+    if (n < 0 || n > 64) return hipErrorInvalidValue;
+    FloatList64 v;
+    for (int i = 0; i < 64; ++i) v.f[i] = i < n ? host[i] : 0.f;
+    hipLaunchKernelGGL(set_list_kernel, dim3(1), dim3(64), 0, s, dst, v, n);
+    return hipGetLastError();
+}
+
 // out[b][c][r] = in[b][r][c] / scale, 32x32 tiles through LDS (both sides coalesced)
 __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, float scale) {
     __shared__ float tile[32][33];

@@ -1258,7 +1258,7 @@ extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float*
     if (method == LDS_METHOD_PLMS) tlist.push_back(table[1]);
     const bool pre = (int)tlist.size() <= kTimePre;
     if (pre) {
-        HIP_TRY(hipMemcpyAsync(s.tp_t, tlist.data(), tlist.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(launch_set_list(s.tp_t, tlist.data(), (int)tlist.size(), st));      // in the launch's arguments: no pageable async copy
         LDS_TRY(time_embedding(u, s.tp_t, s.tp_e1, s.tp_emb, s.tp_proj, (int)tlist.size(), st));
     }
     LDS_TRY(unet_stage_cond(u, cond, uws, uws_bytes, B, T, st));

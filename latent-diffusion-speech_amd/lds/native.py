@@ -343,25 +343,27 @@ class LM:
         check(lib().lds_lm_workspace_bytes(self.h, B, L, max_length, C.byref(nb)))
         return self.ws.get(nb.value, device)
 
-    def encode(self, phone, tone, spk_id=None):
+    def encode(self, phone, tone, spk_id=None, enc_len=None):
+        """enc_len: int32 [B] on the device (real positions per right-padded row) or None"""
         import torch
         B, L = phone.shape
         ph, tn = phone.contiguous().to(torch.int64), tone.contiguous().to(torch.int64)
         sp = spk_id.contiguous().to(torch.int64) if spk_id is not None else None
         ws = self._ws(B, L, 2, phone.device)
         enc = torch.empty(B, L, self.cfg["hidden"], dtype=torch.float32, device=phone.device)
-        check(lib().lds_lm_encode(self.h, _dev(ph, torch.int64), _dev(tn, torch.int64), _dev(sp, torch.int64) if sp is not None else None, _dev(enc),
-                                  _dev(ws), C.c_size_t(ws.numel()), B, L, _stream()))
+        check(lib().lds_lm_encode(self.h, _dev(ph, torch.int64), _dev(tn, torch.int64), _dev(sp, torch.int64) if sp is not None else None,
+                                  _dev(enc_len, torch.int32) if enc_len is not None else None, _dev(enc), _dev(ws), C.c_size_t(ws.numel()), B, L, _stream()))
         return enc
 
-    def generate(self, enc, max_length, do_sample, top_k, top_p, temperature, repetition_penalty, uniforms=None, return_logits=False):
+    def generate(self, enc, max_length, do_sample, top_k, top_p, temperature, repetition_penalty, uniforms=None, return_logits=False, enc_len=None):
         import torch
         B, L, _ = enc.shape
         ws = self._ws(B, L, max_length, enc.device)
         tokens = torch.empty(B, max_length, dtype=torch.int64, device=enc.device)
         logits = torch.empty(max_length - 1, B, self.cfg["sem_vocab"], dtype=torch.float32, device=enc.device) if return_logits else None
         n = C.c_int()
-        check(lib().lds_lm_generate(self.h, _dev(enc.contiguous(), torch.float32), B, L, int(max_length), 1 if do_sample else 0, int(top_k or 0),
+        check(lib().lds_lm_generate(self.h, _dev(enc.contiguous(), torch.float32), _dev(enc_len, torch.int32) if enc_len is not None else None, B, L,
+                                    int(max_length), 1 if do_sample else 0, int(top_k or 0),
                                     C.c_float(top_p), C.c_float(temperature), C.c_float(repetition_penalty),
                                     _dev(uniforms.contiguous(), torch.float32) if uniforms is not None else None, _dev(tokens),
                                     _dev(logits) if logits is not None else None, C.byref(n), _dev(ws), C.c_size_t(ws.numel()), _stream()))

@@ -43,6 +43,11 @@ class Roformer(ParamTree):
                 raise NotImplementedError("encoder and decoder widths must match (reference configs/config.yaml:60-83)")
         if _get(encoder_config, "hidden_act", "gelu") != "gelu" or _get(decoder_config, "hidden_act", "gelu") != "gelu":
             raise NotImplementedError("only hidden_act 'gelu' is built")
+        # one sinusoid table and one LayerNorm epsilon serve both stacks (lds_lm_cfg): configurations whose stacks differ are refused
+        # rather than run with the encoder's values (HF RoFormerConfig defaults: 1536 positions, eps 1e-12)
+        for k, dflt in (("max_position_embeddings", 1536), ("layer_norm_eps", 1e-12)):
+            if _get(encoder_config, k, dflt) != _get(decoder_config, k, dflt):
+                raise NotImplementedError(f"encoder and decoder must agree on {k}")
         cfg = arch.roformer_config(
             n_spk=n_spk, semantic_kmeans_num=semantic_kmeans_num, hidden_size=_get(encoder_config, "hidden_size"),
             num_attention_heads=_get(encoder_config, "num_attention_heads"), intermediate_size=_get(encoder_config, "intermediate_size"),
@@ -97,23 +102,38 @@ class Roformer(ParamTree):
     def forward(self, *a, **k):
         raise NotImplementedError("teacher-forced training forward is out of scope for the MI355X inference build")
 
+    @staticmethod
+    def _mask_to_lengths(attention_mask):
+        """HF padding mask [B,L] (1 = real, 0 = pad) of a RIGHT-padded batch -> int32 [B] real lengths (what the kernels take)"""
+        if attention_mask is None:
+            return None
+        m = attention_mask.to(torch.int64)
+        n = m.sum(-1)
+        L = m.shape[-1]
+        if not bool(((torch.arange(L, device=m.device)[None] < n[:, None]).to(torch.int64) == m).all()) or bool((n < 1).any()):
+            raise NotImplementedError("only right-padded batches are built: every attention_mask row must be ones followed by zeros")
+        return n.to(torch.int32).contiguous()
+
     @torch.no_grad()
-    def encode(self, phone, tone, spk_id=None):
-        """encoder_hidden_states [B,L,hidden] of reference roformer.py:196-204"""
-        return self.native().encode(phone, tone, spk_id if self.spk_emb_enabled else None)
+    def encode(self, phone, tone, spk_id=None, attention_mask=None):
+        """encoder_hidden_states [B,L,hidden] of reference roformer.py:196-214 (rows of padded positions are computed but never read)"""
+        return self.native().encode(phone, tone, spk_id if self.spk_emb_enabled else None, self._mask_to_lengths(attention_mask))
 
     @torch.no_grad()
     def generate(self, phone, tone, attention_mask=None, use_cache=None, max_length=1024, do_sample=True, temperature=1.0, top_k=5, top_p=0.8,
                  repetition_penalty=1.2, num_beams=1, no_repeat_ngram_size=0, early_stopping=True, spk_id=None, end_gate_threshold=None,
                  return_logits=False, **kwargs):
-        if attention_mask is not None:
-            raise NotImplementedError("padding masks are not built (22_infer_tts.py passes attention_mask=None)")
         if num_beams != 1 or no_repeat_ngram_size != 0 or end_gate_threshold is not None:
             raise NotImplementedError("beam search, n-gram blocking and the end gate are not built (22_infer_tts.py uses none of them)")
+        # top_k: 1 .. 64 when sampling (HF's TopKLogitsWarper also accepts None / 0 = no filter and keeps every logit tied with the k-th
+        # one; here exactly k candidates survive, ties broken towards the lower token id -- 22_infer_tts.py:83-98 passes top_k = 5)
+        if do_sample and not (top_k is not None and 1 <= int(top_k) <= 64):
+            raise NotImplementedError("sampling is built for 1 <= top_k <= 64")
+        enc_len = self._mask_to_lengths(attention_mask)      # reference roformer.py:209-236: the encoder's mask and the cross-attention's
         if not phone.is_cuda:
             raise RuntimeError("Roformer.generate needs tensors on a HIP device (no CPU fallback)")
-        enc = self.encode(phone, tone, spk_id)
+        enc = self.native().encode(phone, tone, spk_id if self.spk_emb_enabled else None, enc_len)
         B = enc.shape[0]
         uniforms = torch.rand(max_length - 1, B, device=enc.device) if do_sample else None      # one draw per step and sequence
-        toks, logits = self.native().generate(enc, max_length, do_sample, top_k, top_p, temperature, repetition_penalty, uniforms, return_logits)
+        toks, logits = self.native().generate(enc, max_length, do_sample, top_k, top_p, temperature, repetition_penalty, uniforms, return_logits, enc_len)
         return (toks, logits) if return_logits else toks

@@ -43,9 +43,13 @@ def heads(x, H):
     return x.reshape(B, L, H, C // H).transpose(0, 2, 1, 3)
 
 
-def attend(q, k, v):
-    """softmax(q k^T / sqrt(d)) v, no mask; q [B,H,Lq,d], k/v [B,H,Lk,d] -> [B,Lq,H*d]"""
+def attend(q, k, v, key_len=None):
+    """softmax(q k^T / sqrt(d)) v; q [B,H,Lq,d], k/v [B,H,Lk,d] -> [B,Lq,H*d].  key_len [B] = the padding mask of a right-padded batch
+    (reference roformer.py:209-236: HF adds a -inf bias to the keys at positions >= key_len[b]; their probability is exactly 0)"""
     s = np.matmul(q, k.transpose(0, 1, 3, 2)).astype(f32) / f32(math.sqrt(q.shape[-1]))
+    if key_len is not None:
+        masked = np.arange(k.shape[2])[None, :] >= np.asarray(key_len)[:, None]          # [B, Lk]
+        s = np.where(masked[:, None, None, :], f32(-np.inf), s).astype(f32)
     s = s - s.max(-1, keepdims=True)
     p = np.exp(s).astype(f32)
     p = (p / p.sum(-1, keepdims=True)).astype(f32)
@@ -54,7 +58,7 @@ def attend(q, k, v):
     return o.transpose(0, 2, 1, 3).reshape(B, L, H * d)
 
 
-def _self_attention(w, p, cfg, x, table, pos0, cache=None):
+def _self_attention(w, p, cfg, x, table, pos0, cache=None, key_len=None):
     H = cfg["heads"]
     q = rotary(heads(linear(x, w[p + "self.query.weight"], w[p + "self.query.bias"]), H), table, pos0)
     k = rotary(heads(linear(x, w[p + "self.key.weight"], w[p + "self.key.bias"]), H), table, pos0)
@@ -63,14 +67,14 @@ def _self_attention(w, p, cfg, x, table, pos0, cache=None):
         if "k" in cache:
             k, v = np.concatenate([cache["k"], k], axis=2), np.concatenate([cache["v"], v], axis=2)
         cache["k"], cache["v"] = k, v
-    ctx = attend(q, k, v)
+    ctx = attend(q, k, v, key_len)
     return layer_norm(linear(ctx, w[p + "output.dense.weight"], w[p + "output.dense.bias"]) + x, w[p + "output.LayerNorm.weight"],
                       w[p + "output.LayerNorm.bias"], cfg["eps"])
 
 
-def _cross_attention(w, p, cfg, x, enc_kv):
+def _cross_attention(w, p, cfg, x, enc_kv, enc_len=None):
     q = heads(linear(x, w[p + "self.query.weight"], w[p + "self.query.bias"]), cfg["heads"])
-    ctx = attend(q, enc_kv[0], enc_kv[1])
+    ctx = attend(q, enc_kv[0], enc_kv[1], enc_len)
     return layer_norm(linear(ctx, w[p + "output.dense.weight"], w[p + "output.dense.bias"]) + x, w[p + "output.LayerNorm.weight"],
                       w[p + "output.LayerNorm.bias"], cfg["eps"])
 
@@ -81,8 +85,9 @@ def _ffn(w, p, cfg, x):
                       w[p + "output.LayerNorm.bias"], cfg["eps"])
 
 
-def encoder_forward(w, cfg, phone, tone, spk_id=None):
-    """phone, tone [B,L] int; spk_id [B,L] int or None -> encoder_hidden_states [B,L,hidden]"""
+def encoder_forward(w, cfg, phone, tone, spk_id=None, enc_len=None):
+    """phone, tone [B,L] int; spk_id [B,L] int or None; enc_len [B] = real positions of each right-padded row or None
+    -> encoder_hidden_states [B,L,hidden] (rows at padded positions are computed like HF does; nothing reads them)"""
     p = "text_encoder."
     g, b = w[p + "embeddings.LayerNorm.weight"], w[p + "embeddings.LayerNorm.bias"]
     e = layer_norm(w[p + "embeddings.word_embeddings.weight"][phone] + w[p + "embeddings.token_type_embeddings.weight"][tone], g, b, cfg["eps"])
@@ -92,7 +97,7 @@ def encoder_forward(w, cfg, phone, tone, spk_id=None):
     table = w[p + "encoder.embed_positions.weight"]
     for i in range(cfg["enc_layers"]):
         q = p + f"encoder.layer.{i}."
-        x = _self_attention(w, q + "attention.", cfg, x, table, 0)
+        x = _self_attention(w, q + "attention.", cfg, x, table, 0, key_len=enc_len)
         x = _ffn(w, q, cfg, x)
     return x
 
@@ -106,7 +111,7 @@ def cross_kv(w, cfg, enc):
     return out
 
 
-def decoder_step(w, cfg, tok, pos, caches, enc_kv):
+def decoder_step(w, cfg, tok, pos, caches, enc_kv, enc_len=None):
     """one incremental decoder evaluation: tok [B] at position `pos` -> logits [B, vocab] (modeling_roformer.py:883-950)"""
     p = "semantic_decoder.roformer."
     x = layer_norm(w[p + "embeddings.word_embeddings.weight"][tok][:, None] + w[p + "embeddings.token_type_embeddings.weight"][0],
@@ -115,7 +120,7 @@ def decoder_step(w, cfg, tok, pos, caches, enc_kv):
     for i in range(cfg["dec_layers"]):
         q = p + f"encoder.layer.{i}."
         x = _self_attention(w, q + "attention.", cfg, x, table, pos, caches[i])
-        x = _cross_attention(w, q + "crossattention.", cfg, x, enc_kv[i])
+        x = _cross_attention(w, q + "crossattention.", cfg, x, enc_kv[i], enc_len)
         x = _ffn(w, q, cfg, x)
     c = "semantic_decoder.cls.predictions."
     t = layer_norm(gelu(linear(x, w[c + "transform.dense.weight"], w[c + "transform.dense.bias"])), w[c + "transform.LayerNorm.weight"],
@@ -135,7 +140,7 @@ def pick_token(logits, do_sample, top_k, u):
     return int(min(np.searchsorted(c, f32(u), side="right"), len(c) - 1))
 
 
-def generate(w, cfg, enc, max_length, do_sample=False, top_k=5, uniforms=None):
+def generate(w, cfg, enc, max_length, do_sample=False, top_k=5, uniforms=None, enc_len=None):
     """GenerationMixin greedy / sampling loop as Roformer.generate drives it (roformer.py:179-240): starts from BOS, stops when every
     sequence has produced EOS or at max_length, finished sequences are padded.  Returns (tokens [B, n], logits [n-1, B, vocab])."""
     B = enc.shape[0]
@@ -146,7 +151,7 @@ def generate(w, cfg, enc, max_length, do_sample=False, top_k=5, uniforms=None):
     all_logits = []
     step = 0
     while seq.shape[1] < max_length and unfinished.any():
-        lg = decoder_step(w, cfg, seq[:, -1], seq.shape[1] - 1, caches, kv)
+        lg = decoder_step(w, cfg, seq[:, -1], seq.shape[1] - 1, caches, kv, enc_len)
         all_logits.append(lg)
         nxt = np.array([pick_token(lg[b], do_sample, top_k, None if uniforms is None else uniforms[step, b]) for b in range(B)], dtype=np.int64)
         nxt = np.where(unfinished, nxt, cfg["sem_pad"])

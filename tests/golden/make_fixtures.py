@@ -433,14 +433,14 @@ def roformer_fixtures(path):
         c = probs.float().cumsum(-1)
         return torch.searchsorted(c, u[:, None].contiguous(), right=True).clamp(max=probs.shape[-1] - 1)
 
-    def run(tag, do_sample, max_length, eos_bias=None):
+    def run(tag, do_sample, max_length, eos_bias=None, mask=None):
         if eos_bias is not None:
             m.semantic_decoder.cls.predictions.bias.data[cfg["sem_eos"]] += eos_bias
         del logits[:], enc[:], drawn[:]
         torch.manual_seed(5)
         torch.multinomial = inverse_cdf_multinomial
         try:
-            toks = m.generate(tt(phone), tt(tone), max_length=max_length, do_sample=do_sample, **kw).numpy()
+            toks = m.generate(tt(phone), tt(tone), max_length=max_length, do_sample=do_sample, **dict(kw, attention_mask=None if mask is None else tt(mask))).numpy()
         finally:
             torch.multinomial = real_multinomial
             if eos_bias is not None:
@@ -456,6 +456,12 @@ def roformer_fixtures(path):
     run("sample", True, 40)
     out["eos_bias"] = np.float32(21.0)
     run("eos", True, 40, eos_bias=21.0)
+    # a right-padded batch (two phone lengths in one batch): the mask reaches the encoder's self-attention and, as encoder_attention_mask,
+    # the decoder's cross-attention (reference roformer.py:182,209-214,229-236)
+    lens = np.array([L, 15], dtype=np.int64)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    out["ragged_len"], out["ragged_mask"] = lens, mask
+    out["ragged_enc"] = run("ragged", True, 32, mask=mask)
     hook.remove()
     hook2.remove()
     np.savez_compressed(path("roformer.npz"), **out)

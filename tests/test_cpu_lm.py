@@ -45,8 +45,11 @@ def test_roformer_loud_failures(lm):
         lm.generate(ph, ph, max_length=8)
     with pytest.raises(NotImplementedError):
         lm.generate(ph, ph, num_beams=4)
-    with pytest.raises(NotImplementedError):
-        lm.generate(ph, ph, attention_mask=torch.ones(1, 4))
+    with pytest.raises(NotImplementedError, match="right-padded"):      # only ones-then-zeros masks are built
+        lm.generate(ph, ph, attention_mask=torch.tensor([[1, 0, 1, 1]]))
+    with pytest.raises(NotImplementedError, match="top_k"):
+        lm.generate(ph, ph, top_k=0)
+    assert lm._mask_to_lengths(torch.tensor([[1, 1, 1, 0], [1, 1, 1, 1]])).tolist() == [3, 4]
     with pytest.raises(NotImplementedError):
         lm(ph, ph, ph)
     cfg = yaml.safe_load(open(os.path.join(GOLDEN, "config_lm_like_reference.yaml")))
