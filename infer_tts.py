@@ -91,7 +91,62 @@ def text2semantic(lm, phones, tones, spk_id=1, max_length=1024):
                       repetition_penalty=1.0, num_beams=1, no_repeat_ngram_size=0, early_stopping=True, spk_id=spk, end_gate_threshold=None)
     if tok.shape[0] == 1 and int(tok[0, -1]) == lm.semantic_eos_token_id:      # the reference's check is written for one utterance
         return tok[:, 1:-1]
+    if tok.shape[0] > 1 and bool((tok[:, 1:] >= lm.semantic_eos_token_id).any()):
+        raise ValueError("rows of a batch ended at different lengths (EOS / PAD ids in the result): use text2semantic_rows, which cuts every "
+                         "row at its own EOS, and synthesize_ragged")
     return tok[:, 1:]
+
+
+def text2semantic_rows(lm, phones, tones, spk_id=1, max_length=1024, phone_lengths=None):
+    """A batch of sentences of DIFFERENT lengths (BASELINE configs[4]: 64 sentences per call).  phones / tones [B,L] right-padded,
+    phone_lengths [B] (None = all L): the padding mask goes through the encoder and the cross-attention (reference roformer.py:209-236).
+    Returns one 1-D token tensor per row: BOS stripped, cut before the row's first EOS (rows that finish early are padded by generate;
+    the ids EOS = kmeans_num + 1 and PAD = kmeans_num + 2 have no codebook row and must never reach the unit lookup)."""
+    B, L = phones.shape
+    mask = None
+    if phone_lengths is not None:
+        mask = (torch.arange(L, device=phones.device)[None] < torch.as_tensor(phone_lengths, device=phones.device)[:, None]).to(torch.int64)
+    spk = torch.ones_like(phones) * spk_id
+    tok = lm.generate(phones, tones, attention_mask=mask, use_cache=None, max_length=max_length, do_sample=True, temperature=1.0, top_k=5, top_p=1.0,
+                      repetition_penalty=1.0, num_beams=1, no_repeat_ngram_size=0, early_stopping=True, spk_id=spk, end_gate_threshold=None)
+    tok = tok[:, 1:].cpu()
+    rows = []
+    for b in range(B):
+        stop = (tok[b] >= lm.semantic_eos_token_id).nonzero()
+        n = int(stop[0]) if stop.numel() else tok.shape[1]
+        rows.append(tok[b, :n].to(phones.device))
+    return rows
+
+
+def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None):
+    """Utterances of different lengths through the sampler and the vocoder: rows of equal length run as one batch, and because no kernel
+    reduces across the batch axis (batch invariance) every utterance's mel / waveform is bit-identical to running it alone.
+    token_rows: list of 1-D int64 tensors.  noise_fn(n_utt, T) -> x_T [n_utt,1,M,T] injects the start noise (tests); returns a list of
+    (mel [T,M], wav [T*hop]) in the order of `token_rows`."""
+    from lds import native
+    out = [None] * len(token_rows)
+    by_len = {}
+    for i, r in enumerate(token_rows):
+        by_len.setdefault(int(r.numel()), []).append(i)
+    for T, idx in sorted(by_len.items()):
+        if T == 0:
+            for i in idx:
+                out[i] = (torch.empty(0, codebook.shape[1]), torch.empty(0))
+            continue
+        tok = torch.stack([token_rows[i] for i in idx])
+        units = native.gather_rows(codebook, tok)
+        real = torch.randn
+        if noise_fn is not None:
+            xT = noise_fn(idx, T)
+            torch.randn = lambda *a, **k: xT.clone()
+        try:
+            mel = svc(units, f0=None, volume=None, spk_id=spk_id, infer_speedup=speedup, method=method)
+        finally:
+            torch.randn = real
+        wav = svc.mel2wav(mel, None)
+        for j, i in enumerate(idx):
+            out[i] = (mel[j], wav[j, 0])
+    return out
 
 
 def synthesize(svc, codebook, tokens, spk_id=1, speedup=10, method="dpm-solver", scale_factor=None):

@@ -176,6 +176,57 @@ def test_roformer_ragged_batch_vs_reference(golden, lm_gpu, monkeypatch):
     assert torch.equal(t1[0], toks[1]) and torch.equal(l1[:, 0], logits[:, 1])
 
 
+def test_ragged_batch_phones_to_wav_equals_utterances_alone():
+    """BASELINE configs[4] in small: a batch of sentences with different phone lengths and different token lengths (one row stops at an
+    early EOS) -> per-row tokens -> sampler + vocoder by length bucket; every utterance's mel and waveform equal, bit for bit, what the
+    utterance gives when it runs alone (un-padded, batch of one)."""
+    import infer_tts
+    from lds import init_weights
+    svc, codebook, _ = infer_tts.synthetic_pipeline("cuda", 8)
+    lm = infer_tts.synthetic_lm("cuda")
+    B, L = 4, 12
+    lens = [12, 7, 12, 9]
+    idx = np.arange(B * L).reshape(B, L)
+    phones = torch.from_numpy((idx * 7 % 107 + 1).astype(np.int64)).cuda()
+    tones = torch.from_numpy((idx * 5 % 12).astype(np.int64)).cuda()
+    # one row ends early: EOS bias makes sampling hit EOS after a few tokens for some rows only with these uniforms
+    bias = lm.semantic_decoder.cls.predictions.bias
+    with torch.no_grad():
+        bias[lm.semantic_eos_token_id] += 19.0
+    lm._native = None
+    try:
+        torch.manual_seed(7)
+        rows = infer_tts.text2semantic_rows(lm, phones, tones, 1, 24, phone_lengths=lens)
+        alone = []
+        for b in range(B):
+            torch.manual_seed(7)
+            # the same uniforms column: generate draws rand(max_length - 1, B) -- take row b's column by replaying the full draw
+            u = torch.rand(23, B, device="cuda")[:, b:b + 1].contiguous()
+            real = torch.rand
+            torch.rand = lambda *a, **k: u
+            try:
+                alone.append(infer_tts.text2semantic_rows(lm, phones[b:b + 1, :lens[b]].contiguous(), tones[b:b + 1, :lens[b]].contiguous(), 1, 24)[0])
+            finally:
+                torch.rand = real
+    finally:
+        with torch.no_grad():
+            bias[lm.semantic_eos_token_id] -= 19.0
+        lm._native = None
+    assert len({int(r.numel()) for r in rows}) >= 2, [int(r.numel()) for r in rows]      # really ragged
+    assert all(int(r.max()) < lm.semantic_eos_token_id for r in rows if r.numel())
+    for b in range(B):      # padded-batch tokens = the sentence alone (prefix up to the batch's common stop)
+        n = min(rows[b].numel(), alone[b].numel())
+        assert n > 0 and torch.equal(rows[b][:n], alone[b][:n])
+
+    def noise(idx_list, T):      # per-utterance start noise, a function of the utterance only
+        return torch.stack([torch.from_numpy(init_weights.uniform(f"ragged.xT.{i}", (1, 80, T), 3, -1.7, 1.7)) for i in idx_list]).cuda()
+    got = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise)
+    for i, r in enumerate(rows):
+        one = infer_tts.synthesize_ragged(svc, codebook, [r], 1, 250, "dpm-solver", noise_fn=lambda idx_list, T, i=i: noise([i], T))
+        assert got[i][0].shape == (r.numel(), 80) and got[i][1].shape == (r.numel() * 512,)
+        assert torch.equal(got[i][0], one[0][0]) and torch.equal(got[i][1], one[0][1])
+
+
 def test_roformer_generate_bench_size_vs_oracle(lm_gpu):
     """Parity where the bench runs (VERDICT r2 #4b): 8 utterances x 64 phones -> 512 SAMPLED tokens (max_length 513: KV length, rotary
     positions and the key-split decode attention over the whole range) token-exact against oracle.roformer.generate, per-step logits 2e-5."""
