@@ -115,17 +115,29 @@ def _pmc_key(kernel_name):
     return f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}, 1, false>" if nst else None
 
 
+# source files whose change invalidates a counter summary of a kernel family
+_FAMILY_SOURCES = {"conv_dma": ["conv_dma.hip", "k4p.h", "kernels.h"], "conv_bf3": ["conv_bf3.hip", "k8b3.h", "kernels.h"],
+                   "attention": ["attention_k4p.hip", "k4p.h"], "gn_stream": ["k4p_ops.hip", "k4p.h"]}
+
+
 def pmc_lookup(kernel_name, suffix, field=None):
     """(value, provenance) for `kernel_name` from the newest committed counter summary profiles/*<suffix> (separate rocprofv3 --pmc
-    passes summarised by tools/summarize_pmc.py / summarize_mfma.py).  These are NOT measured in this run: the provenance says which
-    file, which commit and which liblds.so it was taken on, and `stale` is true when that library is not the one loaded now."""
+    passes summarised by tools/summarize_pmc.py / summarize_mfma.py and stamped by tools/stamp_profile.py).  These are NOT measured in
+    this run: the provenance says which file and which commit it was taken on, and `stale` is true when the summary carries no stamp
+    or a source file of the kernel's family has changed since."""
     d, fname = _newest_profile_json(suffix)
     key = _pmc_key(kernel_name)
     if not d or key is None or key not in d.get("kernels", {}):
         return None, None
     v = d["kernels"][key]
-    prov = {"file": "profiles/" + fname, "commit": d.get("commit"), "lib_sha256": d.get("lib_sha256")}
-    prov["stale"] = (d.get("lib_sha256") is None) or (d.get("lib_sha256") != lib_fingerprint())
+    prov = {"file": "profiles/" + fname, "commit": d.get("commit")}
+    srcs = d.get("src_sha256")
+    fam = kernel_name.split("<")[0]
+    if not srcs:
+        prov["stale"] = True
+    else:
+        csrc = os.path.join(ROOT, "latent-diffusion-speech_amd", "csrc")
+        prov["stale"] = any(srcs.get(f) != _sha256(os.path.join(csrc, f)) for f in _FAMILY_SOURCES.get(fam, sorted(srcs)))
     return (v[field] if field else v), prov
 
 
