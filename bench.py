@@ -116,7 +116,7 @@ def _pmc_key(kernel_name):
 
 
 # source files whose change invalidates a counter summary of a kernel family
-_FAMILY_SOURCES = {"conv_dma": ["conv_dma.hip", "k4p.h", "kernels.h"], "conv_bf3": ["conv_bf3.hip", "k8b3.h", "kernels.h"],
+_FAMILY_SOURCES = {"conv_dma": ["conv_dma.hip", "k4p.h"], "conv_bf3": ["conv_bf3.hip", "k8b3.h"],
                    "attention": ["attention_k4p.hip", "k4p.h"], "gn_stream": ["k4p_ops.hip", "k4p.h"]}
 
 
