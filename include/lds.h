@@ -191,6 +191,9 @@ int lds_prof_summary(char* buf, size_t cap);
  * against concurrent forwards on the same handle. */
 #define LDS_GEMM_F32 0
 #define LDS_GEMM_SPLIT_BF16 1
+/* mode 2 (experimental): two fp16 terms per operand (22 significand bits, 4 bytes per element), three products; weights carry a per-layer
+ * power-of-two scale, activations must stay below 65504 in magnitude (csrc/k8b3.h).  Same test suite; error study in profiles/. */
+#define LDS_GEMM_SPLIT_F16 2
 int lds_unet_set_gemm_mode(lds_unet* u, int mode);
 int lds_unet_get_gemm_mode(const lds_unet* u);
 

@@ -67,6 +67,13 @@ int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, c
 int lds_test_dconv_bf3(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, void* stream);
 int lds_bench_dconv_bf3(const lds_dconv_test* a, float* out, int B, int iters, int nprod, float* ms_out, char* cfg_out, size_t cfg_cap,
                         void* stream);
+/* the same through either split-plane format: fmt 0 = three bf16 planes, 1 = two fp16 planes (csrc/k8b3.h); nprod 0 = the format's default */
+int lds_test_dconv_split(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, int fmt, void* stream);
+int lds_bench_dconv_split(const lds_dconv_test* a, float* out, int B, int iters, int nprod, int fmt, float* ms_out, char* cfg_out, size_t cfg_cap,
+                          void* stream);
+int lds_test_split_roundtrip(const float* x, float* out, int B, int C, int T, int fmt, void* stream);
+int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                            const float* beta, const float* scale_shift, int silu, float* out, int B, int fmt, void* stream);
 /* plain [B,C,T] -> K8B3 -> plain: must return the input bit for bit (the three-term split is lossless) */
 int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream);
 /* GroupNorm(+scale/shift)(+SiLU) through the K8B3 streaming pass (statistics from gn_partials_bf3) */

@@ -230,23 +230,29 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // own + partner (each appears once)
     }
     if (tq < T && out_bf3) {
-        // K8B3 output (k8b3.h; the split-bf16 path's to_out projection reads it): rows 8g + 4h + e of a 32-row tile are channel
-        // positions 4h + e of 8-channel block g -- this lane half's 8 bytes of each plane's 16-byte entry
+        // split-plane output (k8b3.h; the split-GEMM path's to_out projection reads it): rows 8g + 4h + e of a 32-row tile are channel
+        // positions 4h + e of 8-channel block g -- this lane half's 8 bytes of each plane's 16-byte entry.  out_bf3: 1 = bf16x3, 2 = fp16x2
         const float rl = 1.0f / l;
         char* ob = reinterpret_cast<char*>(out);
+        const int npl = (out_bf3 == 2) ? 2 : 3;
 #pragma unroll
         for (int i = 0; i < DT; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (i * 32 + 8 * g >= D) break;
                 const int q = (hd * D + i * 32) / 8 + g;
-                unsigned a1, a2, a3, b1, b2, b3;
-                k8_split_pair(o[i][4 * g] * rl, o[i][4 * g + 1] * rl, a1, a2, a3);
-                k8_split_pair(o[i][4 * g + 2] * rl, o[i][4 * g + 3] * rl, b1, b2, b3);
-                const unsigned pa[3] = {a1, a2, a3}, pb[3] = {b1, b2, b3};
+                unsigned pa[3], pb[3];
+                if (out_bf3 == 2) {
+                    sp_split_pair<FMT_F16X2>(o[i][4 * g] * rl, o[i][4 * g + 1] * rl, pa);
+                    sp_split_pair<FMT_F16X2>(o[i][4 * g + 2] * rl, o[i][4 * g + 3] * rl, pb);
+                } else {
+                    sp_split_pair<FMT_BF16X3>(o[i][4 * g] * rl, o[i][4 * g + 1] * rl, pa);
+                    sp_split_pair<FMT_BF16X3>(o[i][4 * g + 2] * rl, o[i][4 * g + 3] * rl, pb);
+                }
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    char* e = ob + ((((long long)b * (C >> 3) + q) * 3 + pl) * Tp + tq + 1) * 16 + h * 8;
+                    if (pl >= npl) break;
+                    char* e = ob + ((((long long)b * (C >> 3) + q) * npl + pl) * Tp + tq + 1) * 16 + h * 8;
                     k8_store_wt(e, k8_u32x2{pa[pl], pb[pl]});
                     if (tq == 0) *reinterpret_cast<k8_u32x2*>(e - 16) = k8_u32x2{0u, 0u};
                     if (tq == T - 1) *reinterpret_cast<k8_u32x2*>(e + 16) = k8_u32x2{0u, 0u};
@@ -314,8 +320,8 @@ static hipError_t attention_any(const float* qk, const float* vt, float* out, in
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
     return attention_any(qk, vt, out, B, C, T, heads, 0, s);
 }
-hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s) {
-    return attention_any(qk, vt, (float*)out, B, C, T, heads, 1, s);
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt) {
+    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, s);
 }
 
 }  // namespace lds

@@ -31,6 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // erf for the GEGLU epilogue: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute (same routine as conv_dma.hip)
 static __device__ __forceinline__ float erf_fast_b(float x) {
@@ -59,16 +60,17 @@ static __device__ __forceinline__ float wave_sum_to_lane63_b(float v) {      // 
 }
 
 // NPROD: bf16 products per fp32 product: 6 (the shipped form), 9 (all), 3 (a1b1 + a1b2 + a2b1: ~2^-16, probe only)
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int FMT = FMT_BF16X3>
 struct Bf3Cfg {
+    static constexpr int NPL = fmt_planes(FMT);                        // planes per 8-channel block: 3 (bf16) or 2 (fp16)
     static constexpr bool SPLIT = BM == 32;                             // 32 x 64 tile, the K-step's k-groups split over the two wave pairs
     static constexpr int TM = SPLIT ? 1 : BM / 64, TN = BN / 64;
     static constexpr int KB = BK / 8;                                   // 8-channel blocks per K-step
     static constexpr int KG = BK / 16;                                  // 16-channel MFMA groups per K-step and tap
     static constexpr int XW = UPS ? (BN / 2 + 2) : ((BN - 1) * STRIDE + KT);      // window entries (frames) per row
-    static constexpr int WCH = KT * KB * 3 * BM / 64;                   // 1 KB weight chunks per stage
+    static constexpr int WCH = KT * KB * NPL * BM / 64;                   // 1 KB weight chunks per stage
     static constexpr int NWI = (WCH + 3) / 4;                           // ... per wave (round-robin; chunks past WCH store zeros)
-    static constexpr int AE = KB * 3 * XW;                              // activation entries per stage
+    static constexpr int AE = KB * NPL * XW;                              // activation entries per stage
     static constexpr int ACH = (AE + 63) / 64;
     static constexpr int NXI = (ACH + 3) / 4;
     static constexpr int PER_TILE = NWI + NXI;                          // VMEM ops per wave per tile (the same for every wave)
@@ -84,9 +86,10 @@ struct Bf3Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "stages exceed the LDS");
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT = FMT_BF16X3>
 struct Bf3Kernel {
-    using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>;
+    static constexpr int NPL = Cfg::NPL;
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, KB = Cfg::KB, XW = Cfg::XW, NWI = Cfg::NWI, NXI = Cfg::NXI;
     static constexpr int G = Cfg::G, KGW = Cfg::KGW, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE, W_FLOATS = Cfg::W_FLOATS;
     static constexpr bool SPLIT = Cfg::SPLIT;
@@ -101,10 +104,10 @@ struct Bf3Kernel {
     int arow;
     int bcol[TN];
     f32x16 acc[TM][TN];
-    u32x4 aop[NB][TM][3], bop[NB][TN][3];
+    u32x4 aop[NB][TM][NPL], bop[NB][TN][NPL];
     float lmu[TN], lrs[TN];   // folded input-LayerNorm statistics of this lane's output columns
     static constexpr bool EARLY = TM * TN == 1;      // single-tile waves fetch the epilogue's residual at kernel start
-    u32x2 rsv[EARLY ? 12 : 1];
+    u32x2 rsv[EARLY ? 4 * NPL : 1];
 
     __device__ __forceinline__ Bf3Kernel(const DmaConvArgs& p_, float* s_) : p(p_), smem(s_) {}
 
@@ -131,9 +134,9 @@ struct Bf3Kernel {
         for (int i = 0; i < NWI; ++i) {
             const int e = (wave + 4 * i) * 64 + lane;           // stage entry = (((tap * KB + kb) * 3 + plane) * BM + m)
             const int m = e % BM, r = e / BM;
-            const int pl = r % 3, kbt = r / 3;
+            const int pl = r % NPL, kbt = r / NPL;
             const int kb = kbt % KB, tap = kbt / KB;
-            woff[i] = (tap < KT) ? ((((tap * (p.Ci >> 3) + kb) * 3 + pl) * p.Mp + m0 + m) * 16) : kOob;
+            woff[i] = (tap < KT) ? ((((tap * (p.Ci >> 3) + kb) * NPL + pl) * p.Mp + m0 + m) * 16) : kOob;
         }
         const int Tp = p.Tsrc + 2;
         const int e0 = UPS ? (((t0 - 1) >> 1) + 1) : (t0 * STRIDE - p.pad + 1);   // first window entry (entry 1 = frame 0)
@@ -143,11 +146,11 @@ struct Bf3Kernel {
             const int r = e / XW, col = e - r * XW;
             xoff[i] = (e < Cfg::AE) ? ((r * Tp + e0 + col) * 16) : kOob;
         }
-        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, KT * p.Ci * p.Mp * 6, 0x00020000);
-        const char* x1b = reinterpret_cast<const char*>(p.x1) + (long long)b * p.C1 * Tp * 6;
-        const char* x2b = p.x2 ? reinterpret_cast<const char*>(p.x2) + (long long)b * p.C2 * Tp * 6 : x1b;
-        rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x1b), 0, p.C1 * Tp * 6, 0x00020000);
-        rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x2b), 0, (p.x2 ? p.C2 : p.C1) * Tp * 6, 0x00020000);
+        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, KT * p.Ci * p.Mp * 2 * NPL, 0x00020000);
+        const char* x1b = reinterpret_cast<const char*>(p.x1) + (long long)b * p.C1 * Tp * 2 * NPL;
+        const char* x2b = p.x2 ? reinterpret_cast<const char*>(p.x2) + (long long)b * p.C2 * Tp * 2 * NPL : x1b;
+        rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x1b), 0, p.C1 * Tp * 2 * NPL, 0x00020000);
+        rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x2b), 0, (p.x2 ? p.C2 : p.C1) * Tp * 2 * NPL, 0x00020000);
         arow = wm * TM * 32 + c;
 #pragma unroll
         for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
@@ -164,13 +167,13 @@ struct Bf3Kernel {
 
     // tile kc -> LDS stage `st`: this wave's share of the weight chunks and of the activation window
     __device__ __forceinline__ void issue_tile(int kc, float* st) {
-        const int ws = kc * (KB * 3 * 16) * p.Mp;                // bytes
+        const int ws = kc * (KB * NPL * 16) * p.Mp;              // bytes
 #pragma unroll
         for (int i = 0; i < NWI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 256), 16, woff[i], ws, 0, 0);
         const int k0 = kc * BK;
         const bool s2 = k0 >= p.C1;                              // C1 % BK == 0: a K-step reads one source only
-        const int xsoff = ((s2 ? k0 - p.C1 : k0) >> 3) * 3 * (p.Tsrc + 2) * 16;
+        const int xsoff = ((s2 ? k0 - p.C1 : k0) >> 3) * NPL * (p.Tsrc + 2) * 16;
         float* xs = st + W_FLOATS;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
@@ -183,17 +186,17 @@ struct Bf3Kernel {
     template <int SLOT>
     __device__ __forceinline__ void load_ops(const float* st, int tap, int kgl) {
         const int kb = 2 * (ks * KGW + kgl) + h;
-        const float* wt = st + ((tap * KB + kb) * 3 * BM + arow) * 4;
-        const float* xs = st + W_FLOATS + (kb * 3 * XW) * 4;
+        const float* wt = st + ((tap * KB + kb) * NPL * BM + arow) * 4;
+        const float* xs = st + W_FLOATS + (kb * NPL * XW) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) aop[SLOT][i][pl] = *reinterpret_cast<const u32x4*>(wt + (pl * BM + i * 32) * 4);
+            for (int pl = 0; pl < NPL; ++pl) aop[SLOT][i][pl] = *reinterpret_cast<const u32x4*>(wt + (pl * BM + i * 32) * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = UPS ? (((t0 + bcol[j] + tap - 1) >> 1) - ((t0 - 1) >> 1)) : (bcol[j] * STRIDE + tap);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bop[SLOT][j][pl] = *reinterpret_cast<const u32x4*>(xs + (pl * XW + col) * 4);
+            for (int pl = 0; pl < NPL; ++pl) bop[SLOT][j][pl] = *reinterpret_cast<const u32x4*>(xs + (pl * XW + col) * 4);
         }
     }
     template <int SLOT, int PA, int PB>
@@ -202,14 +205,22 @@ struct Bf3Kernel {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aop[SLOT][i][PA]), __builtin_bit_cast(bf16x8, bop[SLOT][j][PB]),
-                                                                    acc[i][j], 0, 0, 0);
+                if constexpr (FMT == FMT_F16X2)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aop[SLOT][i][PA]), __builtin_bit_cast(f16x8, bop[SLOT][j][PB]),
+                                                                       acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aop[SLOT][i][PA]), __builtin_bit_cast(bf16x8, bop[SLOT][j][PB]),
+                                                                        acc[i][j], 0, 0, 0);
     }
     template <int SLOT>
     __device__ __forceinline__ void mfma_ops() {
         // smallest terms first: what they add is below the running sum's rounding either way, the order only fixes the result
-        if constexpr (NPROD >= 9) { mfma_pair<SLOT, 2, 2>(); mfma_pair<SLOT, 1, 2>(); mfma_pair<SLOT, 2, 1>(); }
-        if constexpr (NPROD >= 6) { mfma_pair<SLOT, 0, 2>(); mfma_pair<SLOT, 2, 0>(); mfma_pair<SLOT, 1, 1>(); }
+        if constexpr (FMT == FMT_F16X2) {      // a1b1 + a1b2 + a2b1 (+ a2b2 with NPROD 4): the dropped term is below 2^-22 |ab|
+            if constexpr (NPROD >= 4) mfma_pair<SLOT, 1, 1>();
+        } else {
+            if constexpr (NPROD >= 9) { mfma_pair<SLOT, 2, 2>(); mfma_pair<SLOT, 1, 2>(); mfma_pair<SLOT, 2, 1>(); }
+            if constexpr (NPROD >= 6) { mfma_pair<SLOT, 0, 2>(); mfma_pair<SLOT, 2, 0>(); mfma_pair<SLOT, 1, 1>(); }
+        }
         mfma_pair<SLOT, 0, 1>();
         mfma_pair<SLOT, 1, 0>();
         mfma_pair<SLOT, 0, 0>();
@@ -256,20 +267,20 @@ struct Bf3Kernel {
     __device__ __forceinline__ bool res_tile(int tile0, int n) const { return p.res && tile0 < p.plain_from && tile0 < p.Cout && n < p.To; }
     // byte offset of (8-channel block of tile0 + g, plane, frame n), this lane half's 8 bytes
     __device__ __forceinline__ long long k8_off(int Ck, int tile0, int g, int pl, int n) const {
-        return ((((long long)b * (Ck >> 3) + (tile0 >> 3) + g) * 3 + pl) * (p.To + 2) + n + 1) * 16 + h * 8;
+        return ((((long long)b * (Ck >> 3) + (tile0 >> 3) + g) * NPL + pl) * (p.To + 2) + n + 1) * 16 + h * 8;
     }
 
     __device__ __forceinline__ void early_loads() {
         const int tile0 = m0 + wm * 32, n = t0 + wn * 32 + c;
 #pragma unroll
-        for (int e = 0; e < 12; ++e) rsv[e] = u32x2{0u, 0u};
+        for (int e = 0; e < 4 * NPL; ++e) rsv[e] = u32x2{0u, 0u};
         if (res_tile(tile0, n)) {
             const char* rb = reinterpret_cast<const char*>(p.res);
             const int Ck = k8_ck();
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) rsv[g * 3 + pl] = *reinterpret_cast<const u32x2*>(rb + k8_off(Ck, tile0, g, pl, n));
+                for (int pl = 0; pl < NPL; ++pl) rsv[g * NPL + pl] = *reinterpret_cast<const u32x2*>(rb + k8_off(Ck, tile0, g, pl, n));
         }
     }
 
@@ -335,6 +346,14 @@ struct Bf3Kernel {
     // ---- epilogue (phases as in conv_dma.hip: row constants -> residuals of all tiles -> stores) ----
     __device__ __forceinline__ void finalize(bool geglu) {
         const bool ln = p.ln_part != nullptr;
+        if (p.acc_scale != 0.f && p.acc_scale != 1.0f) {      // weights stored times a power of two (fp16 planes): undone exactly
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.acc_scale;
+        }
         if (ln || p.bias) {
             float k1[TM][16], k2[TM][16];
 #pragma unroll
@@ -368,23 +387,26 @@ struct Bf3Kernel {
 
     __device__ __forceinline__ void add_residual(int tile0, int i, int j, int n) {
         if (n >= p.To) return;
-        u32x2 rv[12];
+        u32x2 rv[4 * NPL];
         if constexpr (EARLY) {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) rv[e] = rsv[e];
+            for (int e = 0; e < 4 * NPL; ++e) rv[e] = rsv[e];
         } else {
             const char* rb = reinterpret_cast<const char*>(p.res);
             const int Ck = k8_ck();
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) rv[g * 3 + pl] = *reinterpret_cast<const u32x2*>(rb + k8_off(Ck, tile0, g, pl, n));
+                for (int pl = 0; pl < NPL; ++pl) rv[g * NPL + pl] = *reinterpret_cast<const u32x2*>(rb + k8_off(Ck, tile0, g, pl, n));
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            unsigned lo[NPL], hi[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { lo[pl] = rv[g * NPL + pl][0]; hi[pl] = rv[g * NPL + pl][1]; }
             float a0, a1, a2, a3;
-            k8_join_pair(rv[g * 3][0], rv[g * 3 + 1][0], rv[g * 3 + 2][0], a0, a1);
-            k8_join_pair(rv[g * 3][1], rv[g * 3 + 1][1], rv[g * 3 + 2][1], a2, a3);
+            sp_join_pair<FMT>(lo, a0, a1);
+            sp_join_pair<FMT>(hi, a2, a3);
             acc[i][j][4 * g] += a0; acc[i][j][4 * g + 1] += a1; acc[i][j][4 * g + 2] += a2; acc[i][j][4 * g + 3] += a3;
         }
     }
@@ -438,18 +460,17 @@ struct Bf3Kernel {
             char* ob = reinterpret_cast<char*>(p.out);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                unsigned a1, a2, a3, b1, b2, b3;
-                k8_split_pair(acc[i][j][4 * g], acc[i][j][4 * g + 1], a1, a2, a3);
-                k8_split_pair(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], b1, b2, b3);
-                k8_store_wt(ob + k8_off(Ck, tile0, g, 0, n), k8_u32x2{a1, b1});
-                k8_store_wt(ob + k8_off(Ck, tile0, g, 1, n), k8_u32x2{a2, b2});
-                k8_store_wt(ob + k8_off(Ck, tile0, g, 2, n), k8_u32x2{a3, b3});
+                unsigned pa[NPL], pb[NPL];
+                sp_split_pair<FMT>(acc[i][j][4 * g], acc[i][j][4 * g + 1], pa);
+                sp_split_pair<FMT>(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], pb);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) k8_store_wt(ob + k8_off(Ck, tile0, g, pl, n), k8_u32x2{pa[pl], pb[pl]});
             }
             if (n == 0 || n == p.To - 1) {            // pad frames (entry 0 / entry To + 1 of every row)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NPL; ++pl) {
                         if (n == 0) *reinterpret_cast<u32x2*>(ob + k8_off(Ck, tile0, g, pl, n) - 16) = u32x2{0u, 0u};
                         if (n == p.To - 1) *reinterpret_cast<u32x2*>(ob + k8_off(Ck, tile0, g, pl, n) + 16) = u32x2{0u, 0u};
                     }
@@ -548,10 +569,10 @@ struct Bf3Kernel {
     }
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD>
-__global__ void __launch_bounds__(256, (Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST>::OCC)) conv_bf3_kernel(const DmaConvArgs p) {
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT>
+__global__ void __launch_bounds__(256, (Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>::OCC)) conv_bf3_kernel(const DmaConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    Bf3Kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD> k(p, smem);
+    Bf3Kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT> k(p, smem);
     k.setup();
     k.mainloop();
     k.epilogue();
@@ -559,18 +580,19 @@ __global__ void __launch_bounds__(256, (Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST>
 
 // resnet tail: conv2 (k 3 over h) and the 1x1 shortcut (over the block input) into one set of accumulators, one epilogue
 struct Bf3PairArgs { DmaConvArgs a3, a1; };
-template <int BM, int BN, int BK3, int BK1, int NST>
+template <int BM, int BN, int BK3, int BK1, int NST, int FMT>
 struct Bf3PairCfg {
-    using C3 = Bf3Cfg<BM, BN, 3, 1, false, BK3, NST>;
-    using C1 = Bf3Cfg<BM, BN, 1, 1, false, BK1, NST>;
+    using C3 = Bf3Cfg<BM, BN, 3, 1, false, BK3, NST, FMT>;
+    using C1 = Bf3Cfg<BM, BN, 1, 1, false, BK1, NST, FMT>;
     static constexpr size_t LDS_BYTES = C3::LDS_BYTES > C1::LDS_BYTES ? C3::LDS_BYTES : C1::LDS_BYTES;
     static constexpr int OCC = C3::OCC < C1::OCC ? C3::OCC : C1::OCC;
 };
-template <int BM, int BN, int BK3, int BK1, int NST>
-__global__ void __launch_bounds__(256, (Bf3PairCfg<BM, BN, BK3, BK1, NST>::OCC)) conv_bf3_pair_kernel(const Bf3PairArgs pp) {
+template <int BM, int BN, int BK3, int BK1, int NST, int FMT>
+__global__ void __launch_bounds__(256, (Bf3PairCfg<BM, BN, BK3, BK1, NST, FMT>::OCC)) conv_bf3_pair_kernel(const Bf3PairArgs pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using K3 = Bf3Kernel<BM, BN, 3, 1, false, BK3, NST, 6>;
-    using K1 = Bf3Kernel<BM, BN, 1, 1, false, BK1, NST, 6>;
+    constexpr int NP = FMT == FMT_F16X2 ? 3 : 6;
+    using K3 = Bf3Kernel<BM, BN, 3, 1, false, BK3, NST, NP, FMT>;
+    using K1 = Bf3Kernel<BM, BN, 1, 1, false, BK1, NST, NP, FMT>;
     K1 k1(pp.a1, smem);
     {
         K3 k3(pp.a3, smem);
@@ -590,19 +612,19 @@ __global__ void __launch_bounds__(256, (Bf3PairCfg<BM, BN, BK3, BK1, NST>::OCC))
 static thread_local char g_bcfg[112] = "";
 const char* conv_bf3_last_config() { return g_bcfg; }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD = 6>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT>
 static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
-    using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST>;
+    using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>;
     const int nN = (a.To + BN - 1) / BN;
     dim3 grid((a.Mp / BM) * nN, a.B);
-    auto kern = conv_bf3_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD>;
+    auto kern = conv_bf3_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d P%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, NPROD, grid.x, grid.y,
-             Cfg::LDS_BYTES);
+    snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, FMT == FMT_F16X2 ? "H" : "P",
+             NPROD, grid.x, grid.y, Cfg::LDS_BYTES);
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, a);
     else hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
@@ -645,18 +667,19 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     else { bm = 64; bn = 64; bk = 16; nst = 3; }
 }
 
-template <int BM, int BN, int BK3, int BK1, int NST>
+template <int BM, int BN, int BK3, int BK1, int NST, int FMT>
 static hipError_t launch_bf3_pair_cfg(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
-    using Cfg = Bf3PairCfg<BM, BN, BK3, BK1, NST>;
+    using Cfg = Bf3PairCfg<BM, BN, BK3, BK1, NST, FMT>;
     const int nN = (a1.To + BN - 1) / BN;
     dim3 grid((a1.Mp / BM) * nN, a1.B);
-    auto kern = conv_bf3_pair_kernel<BM, BN, BK3, BK1, NST>;
+    auto kern = conv_bf3_pair_kernel<BM, BN, BK3, BK1, NST, FMT>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d P6 grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, grid.x, grid.y, Cfg::LDS_BYTES);
+    snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d %s grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, FMT == FMT_F16X2 ? "H3" : "P6", grid.x, grid.y,
+             Cfg::LDS_BYTES);
     Bf3PairArgs pp{a3, a1};
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, pp);
@@ -683,19 +706,25 @@ static int bf3_pair_variant(const DmaConvArgs& a3, const DmaConvArgs& a1) {
 }
 bool conv_bf3_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1) { return bf3_pair_variant(a3, a1) != 0; }
 
-hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
+template <int FMT>
+static hipError_t pair_dispatch(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
     switch (bf3_pair_variant(a3, a1)) {      // the 1x1 half runs BK 32 on the k 3 half's tile
-        case 1: return launch_bf3_pair_cfg<32, 64, 32, 32, 2>(a3, a1, s);
-        case 2: return launch_bf3_pair_cfg<64, 128, 16, 32, 2>(a3, a1, s);
-        case 3: return launch_bf3_pair_cfg<64, 64, 16, 32, 3>(a3, a1, s);
+        case 1: return launch_bf3_pair_cfg<32, 64, 32, 32, 2, FMT>(a3, a1, s);
+        case 2: return launch_bf3_pair_cfg<64, 128, 16, 32, 2, FMT>(a3, a1, s);
+        case 3: return launch_bf3_pair_cfg<64, 64, 16, 32, 3, FMT>(a3, a1, s);
         default: return hipErrorNotSupported;
     }
 }
+hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, int fmt, hipStream_t s) {
+    return fmt == FMT_F16X2 ? pair_dispatch<FMT_F16X2>(a3, a1, s) : pair_dispatch<FMT_BF16X3>(a3, a1, s);
+}
 
-#define BCASE(BM, BN, KT, ST, UP, BK, NS) return launch_bf3_cfg<BM, BN, KT, ST, UP, BK, NS>(a, s)
+#define BCASE(BM, BN, KT, ST, UP, BK, NS) return launch_bf3_cfg<BM, BN, KT, ST, UP, BK, NS, (FMT == FMT_F16X2 ? 3 : 6), FMT>(a, s)
 
-// cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto); nprod = 6 (product path), 3 / 9 only for the probe's 128 x 128 x BK32 tile
-hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, hipStream_t s) {
+// cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto); nprod = the format's default (bf16x3: 6, fp16x2: 3) or, on the probe's 128 x 128 x BK32
+// tile only, bf16x3: 3 / 9, fp16x2: 4
+template <int FMT>
+static hipError_t split_dispatch(const DmaConvArgs& a, int cfg, int nprod, hipStream_t s) {
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 32 || a.B <= 0 || a.To <= 0 || a.pad < 0 || a.pad > 1 || a.voc) return hipErrorInvalidValue;
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     int bm, bn, bk, nst;
@@ -706,10 +735,14 @@ hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, hipStream_t
     if (a.Mp % bm) return hipErrorInvalidValue;
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const int tk = bm * 1000 + bn;
-    if (nprod != 6) {
+    if (nprod != (FMT == FMT_F16X2 ? 3 : 6)) {
         if (key == 110 && tk == 128128 && bk == 32 && nst == 2) {
-            if (nprod == 3) return launch_bf3_cfg<128, 128, 1, 1, false, 32, 2, 3>(a, s);
-            if (nprod == 9) return launch_bf3_cfg<128, 128, 1, 1, false, 32, 2, 9>(a, s);
+            if constexpr (FMT == FMT_F16X2) {
+                if (nprod == 4) return launch_bf3_cfg<128, 128, 1, 1, false, 32, 2, 4, FMT>(a, s);
+            } else {
+                if (nprod == 3) return launch_bf3_cfg<128, 128, 1, 1, false, 32, 2, 3, FMT>(a, s);
+                if (nprod == 9) return launch_bf3_cfg<128, 128, 1, 1, false, 32, 2, 9, FMT>(a, s);
+            }
         }
         return hipErrorInvalidValue;
     }
@@ -765,6 +798,10 @@ hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, hipStream_t
         if (bk == 16 && nst == 3) BCASE(64, 64, 3, 1, true, 16, 3);
     }
     return hipErrorInvalidValue;
+}
+hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, int fmt, hipStream_t s) {
+    if (fmt == FMT_F16X2) return split_dispatch<FMT_F16X2>(a, cfg, nprod ? nprod : 3, s);
+    return split_dispatch<FMT_BF16X3>(a, cfg, nprod ? nprod : 6, s);
 }
 
 }  // namespace lds

@@ -94,6 +94,7 @@ struct DmaConvArgs {
     // conv_bf3 only (split-bf16 path, k8b3.h): x1 / x2 / res / out are K8B3 tensors; out_f32 = 1 keeps the K4P-range output channels
     // in fp32 K4P instead (q / k rows for the attention kernel)
     int out_f32;
+    float acc_scale;                    // != 0: the accumulators are multiplied by it first (fp16-plane weights are stored times a power of two)
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
@@ -111,19 +112,20 @@ const char* conv_dma_last_config();
 // struct; activations (x1, x2, res, out) are K8B3 tensors, weights packed [KT][Ci/8][3][Mp][8] bf16 (pack_conv_bf3, model.hip).
 // nprod: bf16 products per fp32 product (6 = product path; 3 / 9 exist for tools/split_bf16_probe.py's error study only).
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, hipStream_t s);
-hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s);
+// fmt: FMT_BF16X3 (three bf16 planes, 6 products) or FMT_F16X2 (two fp16 planes, 3 products; k8b3.h); nprod 0 = the format's default
+hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, int fmt, hipStream_t s);
+hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, int fmt, hipStream_t s);
 bool conv_bf3_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1);
 const char* conv_bf3_last_config();
-// K8B3 helpers (k8b3_ops.hip): plain [B][C][T] <-> K8B3 (channels [c_off, c_off + C) of a tensor with Ctot channels)
-hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s);
-hipError_t launch_from_k8b3(const void* in, float* out, int B, int C, int T, hipStream_t s);
-// GroupNorm(+scale/shift)(+SiLU) of the virtual concat [x1;x2], K8B3 in and out; same statistics path as launch_gn_stream
+// split-plane helpers (k8b3_ops.hip): plain [B][C][T] <-> K8B3 / K8H2 (channels [c_off, c_off + C) of a tensor with Ctot channels); fmt as above
+hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, int fmt = 0);
+hipError_t launch_from_k8b3(const void* in, float* out, int B, int C, int T, hipStream_t s, int fmt = 0);
+// GroupNorm(+scale/shift)(+SiLU) of the virtual concat [x1;x2], split planes in and out; same statistics path as launch_gn_stream
 hipError_t launch_gn_stream_bf3(const void* x1, const void* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                                 const float* beta, const float* scale_shift, int ss_stride, int ss_off, int silu, const float2* gp1,
-                                const float2* gp2, void* y, int B, hipStream_t s);
-hipError_t launch_gn_partials_bf3(const void* x, int C, int T, float2* gp, int B, hipStream_t s);
-hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin, int Tout, hipStream_t s);
+                                const float2* gp2, void* y, int B, hipStream_t s, int fmt = 0);
+hipError_t launch_gn_partials_bf3(const void* x, int C, int T, float2* gp, int B, hipStream_t s, int fmt = 0);
+hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin, int Tout, hipStream_t s, int fmt = 0);
 
 // ---------------------------------------------------------------------------------------------
 // K4P helpers (k4p_ops.hip)
@@ -156,7 +158,7 @@ hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Ti
 // [B][heads][ceil(T/4)][D][4] (key tail zeroed); out K4P [B][C][T]
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s);
 // the same with the output written as a K8B3 tensor (split-bf16 path: the output feeds the to_out projection)
-hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s);
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0);
 
 // ---------------------------------------------------------------------------------------------
 // Small dense layers with N = batch columns (time embedding path)

@@ -225,6 +225,8 @@ struct ConvW {
     float* bias = nullptr;
     int Co = 0, Ci = 0, K = 1, Mp = 0;
     void* w3 = nullptr;      // the same weights as three bf16 planes [KT][Ci/8][3][Mp][8] (split-bf16 path, conv_bf3.hip)
+    void* wh = nullptr;      // ... as two fp16 planes [KT][Ci/8][2][Mp][8] of (w * 2^k); wh_inv = 2^-k undoes the scale in the epilogue
+    float wh_inv = 1.0f;
 };
 
 static int round_mp(int Co) { return Co <= 32 ? 32 : (Co + 63) / 64 * 64; }
@@ -234,30 +236,51 @@ static inline size_t widx(int tap, int k, int m, int Ci, int Mp) {
     return ((((size_t)tap * (Ci / 8) + k / 8) * 2 + (k & 1)) * Mp + m) * 4 + ((k & 7) >> 1);
 }
 
-// Split-bf16 twin of a packed fp32 weight set: every value as three bf16 terms (k8b3.h), [tap][Ci/8][3][Mp][8].  `get(tap, ci, m)` returns
-// the fp32 weight of packed row m.
-template <typename F>
-static bool pack_bf3(Owner& o, int K, int Ci, int Mp, F get, ConvW& out) {
-    std::vector<uint16_t> p((size_t)K * Ci * Mp * 3, 0);
+// Split twins of a packed fp32 weight set (k8b3.h): three bf16 planes [tap][Ci/8][3][Mp][8], or two fp16 planes [tap][Ci/8][2][Mp][8] of
+// the weights times a power of two that puts the largest one in [2^13, 2^14) (fp16's exponent range; `scale_override` != 0 forces the
+// factor: a resnet's conv2 and shortcut share one because they accumulate into the same registers).  `p` = the fp32 packed host copy (widx).
+static float f16_weight_scale(const std::vector<float>& p) {
+    float mx = 0.f;
+    for (float v : p) mx = std::max(mx, fabsf(v));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    return ldexpf(1.0f, 13 - (int)floorf(log2f(mx)));
+}
+static bool pack_split_from_packed(Owner& o, const std::vector<float>& p, int K, int Ci, int Mp, int fmt, float scale_override, ConvW& out) {
+    const int npl = fmt_planes(fmt);
+    const float sc = (fmt == FMT_F16X2) ? (scale_override != 0.f ? scale_override : f16_weight_scale(p)) : 1.0f;
+    std::vector<uint16_t> q((size_t)K * Ci * Mp * npl, 0);
     for (int tap = 0; tap < K; ++tap)
         for (int ci = 0; ci < Ci; ++ci)
             for (int m = 0; m < Mp; ++m) {
-                uint16_t t3[3];
-                split3_host(get(tap, ci, m), t3);
-                for (int pl = 0; pl < 3; ++pl) p[((((size_t)tap * (Ci / 8) + ci / 8) * 3 + pl) * Mp + m) * 8 + (ci & 7)] = t3[pl];
+                uint16_t t3[3] = {0, 0, 0};
+                const float v = p[widx(tap, ci, m, Ci, Mp)];
+                if (fmt == FMT_F16X2) split2h_host(v * sc, t3);
+                else split3_host(v, t3);
+                for (int pl = 0; pl < npl; ++pl) q[((((size_t)tap * (Ci / 8) + ci / 8) * npl + pl) * Mp + m) * 8 + (ci & 7)] = t3[pl];
             }
-    out.w3 = o.upload_bytes(p.data(), p.size() * sizeof(uint16_t));
-    return out.w3 != nullptr;
+    void* d = o.upload_bytes(q.data(), q.size() * sizeof(uint16_t));
+    if (!d) return false;
+    if (fmt == FMT_F16X2) { out.wh = d; out.wh_inv = 1.0f / sc; }
+    else out.w3 = d;
+    return true;
 }
-static bool pack_bf3_from_packed(Owner& o, const std::vector<float>& p, int K, int Ci, int Mp, ConvW& out) {
-    return pack_bf3(o, K, Ci, Mp, [&](int tap, int ci, int m) { return p[widx(tap, ci, m, Ci, Mp)]; }, out);
+static bool read_back(const ConvW& W, std::vector<float>& p) {      // (the packers keep no host copy)
+    p.resize((size_t)W.K * W.Ci * W.Mp);
+    return W.w && hipMemcpy(p.data(), W.w, p.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
 }
-// split-bf16 twin of an already uploaded weight set (read back from the device: the packers keep no host copy)
-static bool make_bf3_twin(Owner& o, ConvW& W) {
-    if (W.w3 || !W.w) return W.w3 != nullptr;
-    std::vector<float> p((size_t)W.K * W.Ci * W.Mp);
-    if (hipMemcpy(p.data(), W.w, p.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return false;
-    return pack_bf3_from_packed(o, p, W.K, W.Ci, W.Mp, W);
+static bool make_split_twin(Owner& o, ConvW& W, int fmt, float scale_override = 0.f) {
+    if (fmt == FMT_F16X2 ? W.wh != nullptr : W.w3 != nullptr) return true;
+    std::vector<float> p;
+    return read_back(W, p) && pack_split_from_packed(o, p, W.K, W.Ci, W.Mp, fmt, scale_override, W);
+}
+static bool make_bf3_twin(Owner& o, ConvW& W) { return make_split_twin(o, W, FMT_BF16X3); }
+// conv2 + shortcut of a resnet: one common fp16 weight scale (they share accumulators in the fused launch)
+static bool make_split_twin_pair(Owner& o, ConvW& A, ConvW& Bw, int fmt) {
+    if (fmt != FMT_F16X2) return make_split_twin(o, A, fmt) && make_split_twin(o, Bw, fmt);
+    std::vector<float> pa, pb;
+    if (!read_back(A, pa) || !read_back(Bw, pb)) return false;
+    const float sc = std::min(f16_weight_scale(pa), f16_weight_scale(pb));
+    return pack_split_from_packed(o, pa, A.K, A.Ci, A.Mp, fmt, sc, A) && pack_split_from_packed(o, pb, Bw.K, Bw.Ci, Bw.Mp, fmt, sc, Bw);
 }
 
 // reference layout w[Co][Ci][K] (or [Co][Ci] for Linear) -> packed
@@ -472,20 +495,22 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
 }
 // the same operator on the split-bf16 path (conv_bf3.hip): K8B3 activations, W.w3 weights
 static int run_dconv_bf3(const ConvW& W, const void* x1, int C1, const void* x2, int C2, int Tsrc, const DOpt& o, void* out, int B, hipStream_t st,
-                         int nprod = 6) {
+                         int nprod = 0, int fmt = FMT_BF16X3) {
     DmaConvArgs a;
     int rc = fill_dconv(W, (const float*)x1, C1, (const float*)x2, C2, Tsrc, o, (float*)out, B, a);
     if (rc != LDS_OK) return rc;
-    if (!W.w3) return fail(LDS_EINVAL, "split-bf16 weights were not packed for this layer");
-    a.w = (const float*)W.w3;
+    const void* wsp = (fmt == FMT_F16X2) ? W.wh : W.w3;
+    if (!wsp) return fail(LDS_EINVAL, "split weights were not packed for this layer");
+    a.w = (const float*)wsp;
     a.x2 = (const float*)x2;      // null = one source (fill_dconv aliases x1 for the fp32 kernel)
     a.out_f32 = o.out_f32;
+    a.acc_scale = (fmt == FMT_F16X2) ? W.wh_inv : 0.f;
     const double flops = 2.0 * B * (double)a.To * (double)W.Co * (double)W.Ci * (double)W.K;
-    const double bytes = 6.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
+    const double bytes = 2.0 * fmt_planes(fmt) * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
     hipError_t e;
     {
         ProfScope ps(st, "conv_bf3", flops, bytes, true);
-        e = launch_conv_bf3(a, o.cfg, nprod, st);
+        e = launch_conv_bf3(a, o.cfg, nprod, fmt, st);
         if (ps.on) {
             std::string cfgs(conv_bf3_last_config());
             std::string nm = "conv_bf3<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
@@ -540,7 +565,7 @@ static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, cons
 }
 
 static int run_dconv_pair_bf3(const ConvW& W3, const void* h, const ConvW& W1, const void* x1, int C1, const void* x2, int C2, int T, const float* bias_pair,
-                              float2* gnpart_out, void* out, int B, hipStream_t st) {
+                              float2* gnpart_out, void* out, int B, hipStream_t st, int fmt) {
     DmaConvArgs a3, a1;
     DOpt o3;
     o3.pad = 1;
@@ -550,18 +575,21 @@ static int run_dconv_pair_bf3(const ConvW& W3, const void* h, const ConvW& W1, c
     o1.gnpart_out = gnpart_out;
     rc = fill_dconv(W1, (const float*)x1, C1, (const float*)x2, C2, T, o1, (float*)out, B, a1);
     if (rc != LDS_OK) return rc;
-    if (!W3.w3 || !W1.w3) return fail(LDS_EINVAL, "split-bf16 weights were not packed for this layer");
-    a3.w = (const float*)W3.w3; a1.w = (const float*)W1.w3;
+    const void *w3p = (fmt == FMT_F16X2) ? W3.wh : W3.w3, *w1p = (fmt == FMT_F16X2) ? W1.wh : W1.w3;
+    if (!w3p || !w1p) return fail(LDS_EINVAL, "split weights were not packed for this layer");
+    if (fmt == FMT_F16X2 && W3.wh_inv != W1.wh_inv) return fail(LDS_EINVAL, "internal: the pair's fp16 weight scales differ");
+    a3.w = (const float*)w3p; a1.w = (const float*)w1p;
+    a3.acc_scale = a1.acc_scale = (fmt == FMT_F16X2) ? W1.wh_inv : 0.f;
     a3.x2 = nullptr; a1.x2 = (const float*)x2;
     a3.bias = nullptr;
     a1.bias = bias_pair;
     const double flops = 2.0 * B * (double)a1.To * (double)W3.Co * ((double)W3.Ci * 3.0 + (double)W1.Ci);
-    const double bytes = 6.0 * ((double)B * (W3.Ci + W1.Ci) * T + (double)W3.Co * (3.0 * W3.Ci + W1.Ci) + (double)B * a1.Cout * a1.To);
+    const double bytes = 2.0 * fmt_planes(fmt) * ((double)B * (W3.Ci + W1.Ci) * T + (double)W3.Co * (3.0 * W3.Ci + W1.Ci) + (double)B * a1.Cout * a1.To);
     if (!conv_bf3_pair_applies(a3, a1)) return 1;
     hipError_t e;
     {
         ProfScope ps(st, "conv_bf3", flops, bytes, true);
-        e = launch_conv_bf3_pair(a3, a1, st);
+        e = launch_conv_bf3_pair(a3, a1, fmt, st);
         if (ps.on) {
             std::string cfgs(conv_bf3_last_config());
             std::string nm = "conv_bf3<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
@@ -579,16 +607,17 @@ static int run_dconv_pair_bf3(const ConvW& W3, const void* h, const ConvW& W1, c
 
 // The UNet's plan is the same in both GEMM modes; these pick the kernel family.  In LDS_GEMM_SPLIT_BF16 mode every activation buffer
 // holds a K8B3 tensor (k8b3.h) instead of a K4P one -- except q / k / v, which stay fp32 for the attention kernel.
-static int dconv_any(bool bf3, const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, hipStream_t st) {
-    return bf3 ? run_dconv_bf3(W, x1, C1, x2, C2, Tsrc, o, out, B, st) : run_dconv(W, x1, C1, x2, C2, Tsrc, o, out, B, st);
+// mode = lds_unet::gemm_mode: 0 exact fp32 (K4P tensors); 1 / 2 split planes, format mode - 1 (k8b3.h)
+static int dconv_any(int mode, const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, hipStream_t st) {
+    return mode ? run_dconv_bf3(W, x1, C1, x2, C2, Tsrc, o, out, B, st, 0, mode - 1) : run_dconv(W, x1, C1, x2, C2, Tsrc, o, out, B, st);
 }
-static hipError_t gn_any(bool bf3, const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma, const float* beta,
+static hipError_t gn_any(int mode, const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma, const float* beta,
                          const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s) {
-    return bf3 ? launch_gn_stream_bf3(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s)
-               : launch_gn_stream(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s);
+    return mode ? launch_gn_stream_bf3(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, mode - 1)
+                : launch_gn_stream(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s);
 }
-static hipError_t to_act_any(bool bf3, const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
-    return bf3 ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s);
+static hipError_t to_act_any(int mode, const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
+    return mode ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s, mode - 1) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s);
 }
 
 // ================================================================================================
@@ -627,8 +656,8 @@ struct lds_unet {
     TfmW mid_t;
     std::vector<UpBlk> up;
     int max_ci = 0;
-    int gemm_mode = LDS_GEMM_F32;      // LDS_GEMM_SPLIT_BF16: every conv / linear through conv_bf3 (lds_unet_set_gemm_mode)
-    bool bf3_packed = false;
+    int gemm_mode = LDS_GEMM_F32;      // LDS_GEMM_SPLIT_BF16 / LDS_GEMM_SPLIT_F16: every conv / linear through conv_bf3 (lds_unet_set_gemm_mode)
+    bool split_packed[2] = {false, false};
 };
 
 static float* up_vec(Owner& o, const float* p, int64_t n) {
@@ -887,35 +916,37 @@ extern "C" int lds_unet_create(const lds_unet_cfg* cfg, int n, const char* const
 
 extern "C" void lds_unet_destroy(lds_unet* u) { delete u; }
 
-// split-bf16 twins of every weight set the forward pass uses (first switch to LDS_GEMM_SPLIT_BF16 only)
-static bool unet_pack_bf3(lds_unet* u) {
+// split twins (format fmt) of every weight set the forward pass uses (first switch to that mode only)
+static bool unet_pack_split(lds_unet* u, int fmt) {
     Owner& o = u->own;
     bool ok = true;
-    auto res = [&](ResnetW& r) { ok = ok && make_bf3_twin(o, r.conv1) && make_bf3_twin(o, r.conv2) && (!r.has_sc || make_bf3_twin(o, r.sc)); };
-    auto tfm = [&](TfmW& t) {
-        ok = ok && make_bf3_twin(o, t.proj_in) && make_bf3_twin(o, t.qkv[0]) && make_bf3_twin(o, t.qkv[1]) && make_bf3_twin(o, t.o[0]) && make_bf3_twin(o, t.o[1]) &&
-             make_bf3_twin(o, t.ff1) && make_bf3_twin(o, t.ff2_out);
+    auto T1 = [&](ConvW& W) { ok = ok && make_split_twin(o, W, fmt); };
+    auto res = [&](ResnetW& r) {
+        T1(r.conv1);
+        if (r.has_sc) ok = ok && make_split_twin_pair(o, r.conv2, r.sc, fmt);
+        else T1(r.conv2);
     };
-    ok = make_bf3_twin(o, u->conv_in) && make_bf3_twin(o, u->conv_in_x) && make_bf3_twin(o, u->conv_in_c) && make_bf3_twin(o, u->conv_out);
+    auto tfm = [&](TfmW& t) { T1(t.proj_in); T1(t.qkv[0]); T1(t.qkv[1]); T1(t.o[0]); T1(t.o[1]); T1(t.ff1); T1(t.ff2_out); };
+    T1(u->conv_in); T1(u->conv_in_x); T1(u->conv_in_c); T1(u->conv_out);
     for (auto& d : u->down) {
         for (auto& r : d.res) res(r);
         for (auto& t : d.att) tfm(t);
-        if (d.has_down) ok = ok && make_bf3_twin(o, d.down);
+        if (d.has_down) T1(d.down);
     }
     res(u->mid_r0); tfm(u->mid_t); res(u->mid_r1);
     for (auto& b : u->up) {
         for (auto& r : b.res) res(r);
         for (auto& t : b.att) tfm(t);
-        if (b.has_up) ok = ok && make_bf3_twin(o, b.up);
+        if (b.has_up) T1(b.up);
     }
     return ok;
 }
 extern "C" int lds_unet_set_gemm_mode(lds_unet* u, int mode) {
-    if (!u || (mode != LDS_GEMM_F32 && mode != LDS_GEMM_SPLIT_BF16)) return fail(LDS_EINVAL, "bad argument");
-    if (mode == LDS_GEMM_SPLIT_BF16 && !u->bf3_packed) {
-        if (u->M % 16 || u->H % 16) return fail(LDS_EINVAL, "split-bf16 mode needs out_dims and n_hidden to be multiples of 16");
-        if (!unet_pack_bf3(u)) return fail(LDS_ENOMEM, "packing the split-bf16 weights failed");
-        u->bf3_packed = true;
+    if (!u || (mode != LDS_GEMM_F32 && mode != LDS_GEMM_SPLIT_BF16 && mode != LDS_GEMM_SPLIT_F16)) return fail(LDS_EINVAL, "bad argument");
+    if (mode != LDS_GEMM_F32 && !u->split_packed[mode - 1]) {
+        if (u->M % 16 || u->H % 16) return fail(LDS_EINVAL, "split GEMM modes need out_dims and n_hidden to be multiples of 16");
+        if (!unet_pack_split(u, mode - 1)) return fail(LDS_ENOMEM, "packing the split weights failed");
+        u->split_packed[mode - 1] = true;
     }
     u->gemm_mode = mode;
     return LDS_OK;
@@ -945,8 +976,8 @@ static size_t k4(int C, int T) { return (size_t)C * (T + 2); }
 
 static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     // floats of one activation tensor: K4P = C * (T + 2); K8B3 (split-bf16 mode) = 1.5x that
-    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
-    auto k4 = [bf3](int C, int Tl) -> size_t { return bf3 ? k8b3_floats(C, Tl) : (size_t)C * (Tl + 2); };
+    const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
+    auto k4 = [bf3](int C, int Tl) -> size_t { return bf3 ? split_floats(bf3 - 1, C, Tl) : (size_t)C * (Tl + 2); };
     const int nb = u->cfg.n_blocks, L = u->cfg.n_layers;
     const int* boc = u->cfg.block_out_channels;
     w.e1 = A.f((size_t)B * u->temb);
@@ -1020,7 +1051,7 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut.
     // GroupNorm(+scale/shift)+SiLU is materialised once per tensor by a streaming pass (gn_stream) so the convolutions stay
     // VALU-free; its statistics come from the partials the producers of x1 / x2 / h1 wrote in their epilogues.
-    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     HIP_TRY(gn_any(bf3, x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.gp(x1), x2 ? w.gp(x2) : nullptr, w.gno, B, st));
     DOpt o1;
     o1.pad = 1; o1.gnpart_out = w.gp(w.h1);
@@ -1029,7 +1060,7 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     const float* res = x1;
     if (r.has_sc) {
         // the shortcut rides in conv2's launch (second reduction into the same accumulators; skip-concat on read: two source pointers)
-        const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st)
+        const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, bf3 - 1)
                            : run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st);
         if (rc != 1) return rc;
         DOpt os;      // no fused variant for these shapes: two launches
@@ -1045,7 +1076,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major (K4P).  Every conv that feeds a
     // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer (QKV / FF1) combines them per column and
     // applies the LayerNorm in its epilogue (weights pre-multiplied by gamma, pack_ln_fold).
-    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     const int C = t.C;
     HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
     DOpt op;
@@ -1059,7 +1090,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
         oq.out_f32 = bf3 ? 1 : 0;                                          // (split-bf16 mode: q / k / v stay fp32 for the attention kernel)
         LDS_TRY(dconv_any(bf3, t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
-        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st));
+        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1));
         else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
         DOpt oo;
         oo.res = h; oo.lnpart_out = w.lnp;
@@ -1094,7 +1125,7 @@ static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_b
     // conv_in is linear in its input channels: the condition's contribution (and the bias) is the same for every evaluation of the run.
     // It is computed here once; an evaluation convolves the 80 sample channels only and adds it as the residual (1008 -> 240 reduction
     // terms per output of conv_in, every NFE).
-    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     HIP_TRY(to_act_any(bf3, cond, w.ck, B, u->H, T, u->H, 0, st));
     DOpt o;
     o.pad = 1;
@@ -1111,7 +1142,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
     const int nb = u->cfg.n_blocks;
-    const bool bf3 = u->gemm_mode == LDS_GEMM_SPLIT_BF16;
+    const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch.
     // e1 = SiLU(linear_1(sinusoid(t))); emb = SiLU(linear_2(e1)) -- every consumer of emb applies SiLU first
     // (resnet.py:610), so only the activated embedding is stored
@@ -1189,7 +1220,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
                 o.ups = 1;
                 LDS_TRY(dconv_any(bf3, b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
             } else {
-                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st));
+                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st, bf3 - 1) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st));
                 LDS_TRY(dconv_any(bf3, b.up, w.upt, b.ch, nullptr, 0, Tn, o, dst, B, st));
             }
             Tl = Tn;
@@ -1730,18 +1761,18 @@ struct TmpDev {
 };
 
 // bf3 = 1: the same operator through the split-bf16 kernel (K8B3 tensors, conv_bf3.hip) with `nprod` bf16 products per fp32 product
-static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream, int bf3 = 0, int nprod = 6) {
+static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream, int bf3 = 0, int nprod = 0, int fmt = 0) {
     hipStream_t st = (hipStream_t)stream;
     Owner own;
     TmpDev tmp;
     ConvW W;
     const int Ci = a->C1 + a->C2, T = a->T;
     bool ok = (a->epilogue == EPI_GEGLU) ? pack_geglu(own, a->w, a->bias, a->Co, Ci, W) : pack_conv(own, a->w, a->bias, a->Co, Ci, a->K, W);
-    if (ok && bf3) ok = make_bf3_twin(own, W);
+    if (ok && bf3) ok = make_split_twin(own, W, fmt);
     if (!ok) return fail(LDS_ENOMEM, "test dconv: upload failed");
-    auto act_floats = [&](int C, int Tl) { return bf3 ? (size_t)B * k8b3_floats(C, Tl) : (size_t)B * C * (Tl + 2); };
-    auto to_act = [&](const float* src, float* dst, int C, int Tl) { return bf3 ? launch_to_k8b3(src, dst, B, C, Tl, C, 0, st) : launch_to_k4p(src, dst, B, C, Tl, C, 0, st); };
-    auto from_act = [&](const float* src, float* dst, int C, int Tl) { return bf3 ? launch_from_k8b3(src, dst, B, C, Tl, st) : launch_from_k4p(src, dst, B, C, Tl, st); };
+    auto act_floats = [&](int C, int Tl) { return bf3 ? (size_t)B * split_floats(fmt, C, Tl) : (size_t)B * C * (Tl + 2); };
+    auto to_act = [&](const float* src, float* dst, int C, int Tl) { return bf3 ? launch_to_k8b3(src, dst, B, C, Tl, C, 0, st, fmt) : launch_to_k4p(src, dst, B, C, Tl, C, 0, st); };
+    auto from_act = [&](const float* src, float* dst, int C, int Tl) { return bf3 ? launch_from_k8b3(src, dst, B, C, Tl, st, fmt) : launch_from_k4p(src, dst, B, C, Tl, st); };
     float* k1 = tmp.f(act_floats(a->C1, T));
     float* k2 = a->C2 ? tmp.f(act_floats(a->C2, T)) : nullptr;
     if (!k1 || (a->C2 && !k2)) return fail(LDS_ENOMEM, "test dconv: alloc failed");
@@ -1774,7 +1805,7 @@ static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, i
         if (a->v_split > 1) o.vt_D = a->v_split;      // value third in attention's VT layout with this head dim
     }
     o.lnpart_out = (float2*)lnpart;
-    auto run = [&]() { return bf3 ? run_dconv_bf3(W, k1, a->C1, k2, a->C2, T, o, kout, B, st, nprod) : run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st); };
+    auto run = [&]() { return bf3 ? run_dconv_bf3(W, k1, a->C1, k2, a->C2, T, o, kout, B, st, nprod, fmt) : run_dconv(W, k1, a->C1, k2, a->C2, T, o, kout, B, st); };
     int r = run();
     if (r == LDS_OK && iters > 0 && ms_out) {
         hipEvent_t e0, e1;
@@ -1823,13 +1854,23 @@ extern "C" int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int i
     if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_dma_last_config());
     return r;
 }
+extern "C" int lds_test_dconv_split(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, int fmt, void* stream) {
+    if (!a || !out || (fmt != FMT_BF16X3 && fmt != FMT_F16X2)) return fail(LDS_EINVAL, "bad argument");
+    return dconv_test_impl(a, out, lnpart, B, 0, nullptr, stream, 1, nprod, fmt);
+}
 extern "C" int lds_test_dconv_bf3(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, void* stream) {
-    if (!a || !out) return fail(LDS_EINVAL, "bad argument");
-    return dconv_test_impl(a, out, lnpart, B, 0, nullptr, stream, 1, nprod);
+    return lds_test_dconv_split(a, out, lnpart, B, nprod, FMT_BF16X3, stream);
+}
+extern "C" int lds_bench_dconv_split(const lds_dconv_test* a, float* out, int B, int iters, int nprod, int fmt, float* ms_out, char* cfg_out, size_t cfg_cap,
+                                     void* stream) {
+    if (!a || !out || !ms_out || iters <= 0 || (fmt != FMT_BF16X3 && fmt != FMT_F16X2)) return fail(LDS_EINVAL, "bad argument");
+    int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream, 1, nprod, fmt);
+    if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_bf3_last_config());
+    return r;
 }
 extern "C" int lds_bench_dconv_bf3(const lds_dconv_test* a, float* out, int B, int iters, int nprod, float* ms_out, char* cfg_out, size_t cfg_cap, void* stream) {
     if (!a || !out || !ms_out || iters <= 0) return fail(LDS_EINVAL, "bad argument");
-    int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream, 1, nprod);
+    int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream, 1, nprod, FMT_BF16X3);
     if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_bf3_last_config());
     return r;
 }
@@ -2034,40 +2075,46 @@ extern "C" int lds_test_conv_transpose(const float* x, const float* w, const flo
     return r;
 }
 
-extern "C" int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream) {
+extern "C" int lds_test_split_roundtrip(const float* x, float* out, int B, int C, int T, int fmt, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!x || !out || (C & 7)) return fail(LDS_EINVAL, "bad argument");
+    if (!x || !out || (C & 7) || (fmt != FMT_BF16X3 && fmt != FMT_F16X2)) return fail(LDS_EINVAL, "bad argument");
     TmpDev tmp;
-    float* k = tmp.f((size_t)B * k8b3_floats(C, T));
+    float* k = tmp.f((size_t)B * split_floats(fmt, C, T));
     if (!k) return fail(LDS_ENOMEM, "alloc");
-    HIP_TRY(launch_to_k8b3(x, k, B, C, T, C, 0, st));
-    HIP_TRY(launch_from_k8b3(k, out, B, C, T, st));
+    HIP_TRY(launch_to_k8b3(x, k, B, C, T, C, 0, st, fmt));
+    HIP_TRY(launch_from_k8b3(k, out, B, C, T, st, fmt));
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
 }
+extern "C" int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream) { return lds_test_split_roundtrip(x, out, B, C, T, FMT_BF16X3, stream); }
 
 extern "C" int lds_test_gn_apply_bf3(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                                      const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream) {
+    return lds_test_gn_apply_split(x1, x2, C1, C2, T, groups, eps, gamma, beta, scale_shift, silu, out, B, FMT_BF16X3, stream);
+}
+extern "C" int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
+                                       const float* beta, const float* scale_shift, int silu, float* out, int B, int fmt, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (fmt != FMT_BF16X3 && fmt != FMT_F16X2) return fail(LDS_EINVAL, "bad argument");
     Owner own;
     TmpDev tmp;
     const int C = C1 + C2, nT = (T + 31) / 32;
     float* g = up_vec(own, gamma, C);
     float* be = up_vec(own, beta, C);
-    float* k1 = tmp.f((size_t)B * k8b3_floats(C1, T));
-    float* k2 = C2 ? tmp.f((size_t)B * k8b3_floats(C2, T)) : nullptr;
-    float* ky = tmp.f((size_t)B * k8b3_floats(C, T));
+    float* k1 = tmp.f((size_t)B * split_floats(fmt, C1, T));
+    float* k2 = C2 ? tmp.f((size_t)B * split_floats(fmt, C2, T)) : nullptr;
+    float* ky = tmp.f((size_t)B * split_floats(fmt, C, T));
     float* p1 = tmp.f((size_t)B * (C1 / 16) * nT * 2);
     float* p2 = C2 ? tmp.f((size_t)B * (C2 / 16) * nT * 2) : nullptr;
     if (!g || !be || !k1 || (C2 && (!k2 || !p2)) || !ky || !p1) return fail(LDS_ENOMEM, "alloc");
-    HIP_TRY(launch_to_k8b3(x1, k1, B, C1, T, C1, 0, st));
-    HIP_TRY(launch_gn_partials_bf3(k1, C1, T, (float2*)p1, B, st));
+    HIP_TRY(launch_to_k8b3(x1, k1, B, C1, T, C1, 0, st, fmt));
+    HIP_TRY(launch_gn_partials_bf3(k1, C1, T, (float2*)p1, B, st, fmt));
     if (C2) {
-        HIP_TRY(launch_to_k8b3(x2, k2, B, C2, T, C2, 0, st));
-        HIP_TRY(launch_gn_partials_bf3(k2, C2, T, (float2*)p2, B, st));
+        HIP_TRY(launch_to_k8b3(x2, k2, B, C2, T, C2, 0, st, fmt));
+        HIP_TRY(launch_gn_partials_bf3(k2, C2, T, (float2*)p2, B, st, fmt));
     }
-    HIP_TRY(launch_gn_stream_bf3(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (const float2*)p1, (const float2*)p2, ky, B, st));
-    HIP_TRY(launch_from_k8b3(ky, out, B, C, T, st));
+    HIP_TRY(launch_gn_stream_bf3(k1, k2, C1, C2, T, groups, eps, g, be, scale_shift, 2 * C, 0, silu, (const float2*)p1, (const float2*)p2, ky, B, st, fmt));
+    HIP_TRY(launch_from_k8b3(ky, out, B, C, T, st, fmt));
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
 }

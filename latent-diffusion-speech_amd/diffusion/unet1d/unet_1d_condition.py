@@ -59,7 +59,7 @@ class UNet1DConditionModel(ParamTree):
     def set_gemm_mode(self, mode):
         """"f32" (default): every conv / linear on the exact-fp32 MFMA.  "split_bf16": the same layers as fp32-equivalent split-bf16
         GEMMs (three bf16 terms per operand, six products, fp32 accumulate; csrc/conv_bf3.hip) -- not part of the reference's API."""
-        if mode not in ("f32", "split_bf16"):
+        if mode not in ("f32", "split_bf16", "split_f16"):
             raise ValueError(mode)
         self._gemm_mode = mode
         if self._native is not None:

@@ -55,7 +55,8 @@ EXPORTS = [
 TEST_EXPORTS = [
     "lds_test_conv", "lds_test_dconv", "lds_bench_dconv", "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p",
     "lds_test_ln_chain_k4p", "lds_test_attention_k4p", "lds_test_conv_transpose", "lds_test_voc_step", "lds_test_dconv_bf3",
-    "lds_bench_dconv_bf3", "lds_test_k8b3_roundtrip", "lds_test_gn_apply_bf3"]
+    "lds_bench_dconv_bf3", "lds_test_k8b3_roundtrip", "lds_test_gn_apply_bf3", "lds_test_dconv_split", "lds_bench_dconv_split",
+    "lds_test_split_roundtrip", "lds_test_gn_apply_split"]
 
 
 def lib():
@@ -152,7 +153,7 @@ class UNet:
 
     def set_gemm_mode(self, mode):
         """0 / "f32": exact-fp32 MFMA (default); 1 / "split_bf16": fp32-equivalent split-bf16 GEMMs (include/lds.h)"""
-        m = {"f32": 0, "split_bf16": 1}.get(mode, mode)
+        m = {"f32": 0, "split_bf16": 1, "split_f16": 2}.get(mode, mode)
         check(lib().lds_unet_set_gemm_mode(self.h, int(m)))
 
     def gemm_mode(self):

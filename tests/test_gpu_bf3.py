@@ -13,7 +13,11 @@ torch = pytest.importorskip("torch")
 from test_gpu_k4p import U, dev, ref_dconv, relmax, stream  # noqa: E402
 
 
-def run_dconv_bf3(x1, w, bias=None, x2=None, stride=1, pad=0, ups=0, res=None, epi=0, plain_out=0, v_split=0, cfg=0, want_ln=False, nprod=6):
+FMTS = [0, 1]      # csrc/k8b3.h: 0 = three bf16 planes (lossless, 6 products), 1 = two fp16 planes (22-bit operands, 3 products)
+FMT_IDS = ["bf16x3", "f16x2"]
+
+
+def run_dconv_bf3(x1, w, bias=None, x2=None, stride=1, pad=0, ups=0, res=None, epi=0, plain_out=0, v_split=0, cfg=0, want_ln=False, nprod=0, fmt=0):
     from lds import native
     B, C1, T = x1.shape
     C2 = 0 if x2 is None else x2.shape[1]
@@ -36,10 +40,27 @@ def run_dconv_bf3(x1, w, bias=None, x2=None, stride=1, pad=0, ups=0, res=None, e
     a.epilogue, a.plain_out, a.v_split, a.cfg = epi, plain_out, v_split, cfg
     out = torch.full((B, Cout, To), float("nan"), dtype=torch.float32, device="cuda")
     ln = torch.full((B, Cout // 32, To, 2), float("nan"), dtype=torch.float32, device="cuda") if want_ln else None
-    native.check(native.lib().lds_test_dconv_bf3(ct.byref(a), ct.c_void_p(out.data_ptr()), ct.c_void_p(ln.data_ptr()) if want_ln else None, B,
-                                                 nprod, stream()))
+    native.check(native.lib().lds_test_dconv_split(ct.byref(a), ct.c_void_p(out.data_ptr()), ct.c_void_p(ln.data_ptr()) if want_ln else None, B,
+                                                   nprod, fmt, stream()))
     torch.cuda.synchronize()
     return (out.cpu().numpy(), ln.cpu().numpy()) if want_ln else out.cpu().numpy()
+
+
+def test_k8h2_roundtrip_error_bound():
+    """the fp16 pair is NOT lossless: |v - (v1 + v2)| <= 2^-22 |v| in fp16's normal range, and an absolute 2^-25 below 2^-3 (second term
+    subnormal); magnitudes beyond 65504 overflow (documented precondition of the format)"""
+    from lds import native
+    B, C, T = 2, 64, 300
+    x = U("rth", (B, C, T), -3, 3)
+    x.reshape(-1)[:8] = np.array([0.0, 1.0, -1.0, 0.1, 1 / 3, 1000.5, 6.0e4, 1e-3], dtype=np.float32)
+    out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    dx = dev(x)
+    native.check(native.lib().lds_test_split_roundtrip(ct.c_void_p(dx.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, 1, stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    err = np.abs(got.astype(np.float64) - x)
+    assert (err <= np.maximum(np.abs(x) * 2.0 ** -22, 2.0 ** -25)).all(), float((err / np.maximum(np.abs(x), 2.0 ** -3)).max())
+    assert (err > 0).any()
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 70), (1, 8, 1), (3, 336, 513)])
@@ -98,8 +119,9 @@ BCASES = {
 }
 
 
+@pytest.mark.parametrize("fmt", FMTS, ids=FMT_IDS)
 @pytest.mark.parametrize("name", list(BCASES))
-def test_conv_bf3(name):
+def test_conv_bf3(name, fmt):
     B, C1, C2, T, Co, K, kw = BCASES[name]
     kw = dict(kw)
     x1 = U(name + ".x1", (B, C1, T), -2, 2)
@@ -116,14 +138,15 @@ def test_conv_bf3(name):
     if kw.pop("res", False):
         args["res"] = U(name + ".res", ref0.shape, -1, 1)
     ref = ref_dconv(x1, w, **args)
-    out = run_dconv_bf3(x1, w, plain_out=kw.get("plain_out", 0), v_split=kw.get("v_split", 0), cfg=kw.get("cfg", 0), **args)
+    out = run_dconv_bf3(x1, w, plain_out=kw.get("plain_out", 0), v_split=kw.get("v_split", 0), cfg=kw.get("cfg", 0), fmt=fmt, **args)
     assert out.shape == ref.shape
     assert np.isfinite(out).all()
     assert relmax(out, ref) < 2e-5, relmax(out, ref)
 
 
+@pytest.mark.parametrize("fmt", FMTS, ids=FMT_IDS)
 @pytest.mark.parametrize("C,heads,T", [(64, 2, 72), (96, 2, 37), (128, 2, 50)])
-def test_conv_bf3_value_layout(C, heads, T):
+def test_conv_bf3_value_layout(C, heads, T, fmt):
     """QKV projection of the split-bf16 path: q, k leave in fp32 K4P (the attention kernel's input), v in its VT layout"""
     from lds import native
     B, D = 2, C // heads
@@ -138,7 +161,7 @@ def test_conv_bf3_value_layout(C, heads, T):
     a.w, a.bias, a.Co, a.K, a.stride, a.pad, a.ups = wk.ctypes.data, None, 3 * C, 1, 1, 0, 0
     a.res, a.epilogue, a.plain_out, a.v_split, a.cfg = None, 0, 0, D, 0
     out = torch.full((B * 2 * C * T + B * C * T4,), float("nan"), dtype=torch.float32, device="cuda")
-    native.check(native.lib().lds_test_dconv_bf3(ct.byref(a), ct.c_void_p(out.data_ptr()), None, B, 6, stream()))
+    native.check(native.lib().lds_test_dconv_split(ct.byref(a), ct.c_void_p(out.data_ptr()), None, B, 0, fmt, stream()))
     torch.cuda.synchronize()
     o = out.cpu().numpy()
     qk = o[:B * 2 * C * T].reshape(B, 2 * C, T)
@@ -152,12 +175,13 @@ def test_conv_bf3_value_layout(C, heads, T):
     assert (vt.transpose(0, 1, 3, 2, 4).reshape(B, C, T4)[:, :, T:] == 0).all()
 
 
+@pytest.mark.parametrize("fmt", FMTS, ids=FMT_IDS)
 @pytest.mark.parametrize("cfg", [0, 64064322, 32064322])
-def test_conv_bf3_layernorm_partials(cfg):
+def test_conv_bf3_layernorm_partials(cfg, fmt):
     B, C, T = 2, 128, 70
     x = U("blnp.x", (B, 64, T), -2, 2)
     w = U("blnp.w", (C, 64, 1)) / np.float32(8.0)
-    out, ln = run_dconv_bf3(x, w, want_ln=True, cfg=cfg)
+    out, ln = run_dconv_bf3(x, w, want_ln=True, cfg=cfg, fmt=fmt)
     t = out.reshape(B, C // 32, 32, T).astype(np.float64)
     assert np.abs(ln[..., 0] - t.mean(2)).max() < 1e-5
     assert np.abs(ln[..., 1] - ((t - t.mean(2, keepdims=True)) ** 2).sum(2)).max() < 1e-3
@@ -165,7 +189,8 @@ def test_conv_bf3_layernorm_partials(cfg):
 
 @pytest.mark.parametrize("C1,C2,T,silu,ss", [(128, 0, 64, 1, False), (80, 176, 50, 1, False), (128, 0, 64, 1, True), (256, 0, 37, 0, False),
                                              (512, 384, 128, 1, False), (256, 256, 512, 1, True), (512, 0, 700, 1, False), (64, 64, 3000, 1, True)])
-def test_gn_apply_bf3(C1, C2, T, silu, ss):
+@pytest.mark.parametrize("fmt", FMTS, ids=FMT_IDS)
+def test_gn_apply_bf3(C1, C2, T, silu, ss, fmt):
     """streaming GroupNorm over K8B3 tensors, statistics from the stand-alone partials pass"""
     from lds import native
     from oracle import unet1d
@@ -176,9 +201,9 @@ def test_gn_apply_bf3(C1, C2, T, silu, ss):
     sst = U(f"bgn{C}.ss", (B, 2 * C), -0.5, 0.5) if ss else None
     out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
     d1, d2, dss = dev(x1), (dev(x2) if C2 else None), (dev(sst) if ss else None)
-    native.check(native.lib().lds_test_gn_apply_bf3(ct.c_void_p(d1.data_ptr()), ct.c_void_p(d2.data_ptr()) if C2 else None, C1, C2, T, 8,
-                                                    ct.c_float(1e-5), ct.c_void_p(g.ctypes.data), ct.c_void_p(be.ctypes.data),
-                                                    ct.c_void_p(dss.data_ptr()) if ss else None, silu, ct.c_void_p(out.data_ptr()), B, stream()))
+    native.check(native.lib().lds_test_gn_apply_split(ct.c_void_p(d1.data_ptr()), ct.c_void_p(d2.data_ptr()) if C2 else None, C1, C2, T, 8,
+                                                      ct.c_float(1e-5), ct.c_void_p(g.ctypes.data), ct.c_void_p(be.ctypes.data),
+                                                      ct.c_void_p(dss.data_ptr()) if ss else None, silu, ct.c_void_p(out.data_ptr()), B, fmt, stream()))
     torch.cuda.synchronize()
     x = x1 if x2 is None else np.concatenate([x1, x2], axis=1)
     ref = unet1d.group_norm(x, g, be, 8, 1e-5)

@@ -22,8 +22,8 @@ def relmax(a, b):
 
 
 # every whole-path test runs in both GEMM modes at the SAME tolerances: "f32" = exact-fp32 MFMA (the default, the bench's `value`),
-# "split_bf16" = fp32-equivalent split-bf16 GEMMs (csrc/conv_bf3.hip; UNet1DConditionModel.set_gemm_mode)
-@pytest.fixture(scope="module", params=["f32", "split_bf16"])
+# "split_bf16" = fp32-equivalent split-bf16 GEMMs (csrc/conv_bf3.hip; UNet1DConditionModel.set_gemm_mode), "split_f16" = two fp16 planes
+@pytest.fixture(scope="module", params=["f32", "split_bf16", "split_f16"])
 def unit2mel_gpu(request):
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     from diffusion.unit2mel import Unit2Mel

@@ -48,7 +48,7 @@ def make_args(x1, x2, w, K, pad, cfg):
     return a
 
 
-def run(kind, x1, x2, w, K, pad, cfg, nprod, iters):
+def run(kind, x1, x2, w, K, pad, cfg, nprod, iters, fmt=0):
     """-> (out tensor, ms per launch, configuration string)"""
     L = native.lib()
     B, _, T = x1.shape
@@ -58,7 +58,7 @@ def run(kind, x1, x2, w, K, pad, cfg, nprod, iters):
     if kind == "f32":
         rc = L.lds_bench_dconv(ct.byref(a), ct.c_void_p(out.data_ptr()), B, iters, ct.byref(ms), cs, 160, stream())
     else:
-        rc = L.lds_bench_dconv_bf3(ct.byref(a), ct.c_void_p(out.data_ptr()), B, iters, nprod, ct.byref(ms), cs, 160, stream())
+        rc = L.lds_bench_dconv_split(ct.byref(a), ct.c_void_p(out.data_ptr()), B, iters, nprod, fmt, ct.byref(ms), cs, 160, stream())
     if rc != 0:
         return None, None, L.lds_last_error().decode()
     torch.cuda.synchronize()
@@ -101,18 +101,27 @@ def main():
         ent["kernels"]["exact_f32"] = {"cfg": cs, "us": ms * 1e3, "tflops": flops / (ms * 1e-3) / 1e12, **errors(o, ref64)}
         print(f"{name:34s} f32  {cs:56s} {ms * 1e3:8.1f} us {flops / (ms * 1e-3) / 1e12:6.1f} TF  max {ent['kernels']['exact_f32']['max_rel_rms']:.2e} "
               f"rms {ent['kernels']['exact_f32']['rms_rel_rms']:.2e}", flush=True)
-        best = None
-        for cfg in cfgs:
-            o, ms, cs = run("bf3", x1, x2, w, K, pad, cfg, 6, args.iters)
-            if o is None:
-                print(f"{name:34s} bf3 cfg {cfg}: {cs[:90]}", flush=True)
-                continue
-            e = errors(o, ref64)
-            rec = {"cfg": cs, "auto": cfg == 0, "us": ms * 1e3, "tflops": flops / (ms * 1e-3) / 1e12, **e}
-            ent["kernels"].setdefault("split_bf16_P6", []).append(rec)
-            print(f"{name:34s} bf3  {cs:56s} {ms * 1e3:8.1f} us {rec['tflops']:6.1f} TF  max {e['max_rel_rms']:.2e} rms {e['rms_rel_rms']:.2e}", flush=True)
-            if best is None or rec["us"] < best["us"]:
-                best = rec
+        best, best_h = None, None
+        for fmt, tag, key in ((0, "bf3 ", "split_bf16_P6"), (1, "f16 ", "split_f16_H3")):
+            for cfg in cfgs:
+                o, ms, cs = run("bf3", x1, x2, w, K, pad, cfg, 0, args.iters, fmt)
+                if o is None:
+                    print(f"{name:34s} {tag} cfg {cfg}: {cs[:90]}", flush=True)
+                    continue
+                e = errors(o, ref64)
+                rec = {"cfg": cs, "auto": cfg == 0, "us": ms * 1e3, "tflops": flops / (ms * 1e-3) / 1e12, **e}
+                ent["kernels"].setdefault(key, []).append(rec)
+                print(f"{name:34s} {tag} {cs:56s} {ms * 1e3:8.1f} us {rec['tflops']:6.1f} TF  max {e['max_rel_rms']:.2e} rms {e['rms_rel_rms']:.2e}", flush=True)
+                if fmt == 0 and (best is None or rec["us"] < best["us"]):
+                    best = rec
+                if fmt == 1 and (best_h is None or rec["us"] < best_h["us"]):
+                    best_h = rec
+        if K == 1 and Co % 128 == 0:
+            o, ms, cs = run("bf3", x1, x2, w, K, pad, 128128322, 4, args.iters, 1)      # fp16 planes with the fourth product (a2 b2)
+            if o is not None:
+                e = errors(o, ref64)
+                ent["kernels"]["split_f16_H4"] = {"cfg": cs, "us": ms * 1e3, "tflops": flops / (ms * 1e-3) / 1e12, **e}
+                print(f"{name:34s} H4   {cs:56s} {ms * 1e3:8.1f} us  max {e['max_rel_rms']:.2e} rms {e['rms_rel_rms']:.2e}", flush=True)
         if K == 1 and Co % 128 == 0:      # the product-count study on the one tile that has the three variants
             for nprod in (3, 9):
                 o, ms, cs = run("bf3", x1, x2, w, K, pad, 128128322, nprod, args.iters)
@@ -125,6 +134,10 @@ def main():
         ent["speedup_launch"] = f32["us"] / best["us"]
         ent["error_ratio_max"] = best["max_rel_rms"] / f32["max_rel_rms"]
         ent["error_ratio_rms"] = best["rms_rel_rms"] / f32["rms_rel_rms"]
+        ent["best_split_f16"] = best_h
+        ent["f16_speedup_launch"] = f32["us"] / best_h["us"]
+        ent["f16_error_ratio_max"] = best_h["max_rel_rms"] / f32["max_rel_rms"]
+        ent["f16_error_ratio_rms"] = best_h["rms_rel_rms"] / f32["rms_rel_rms"]
         res["shapes"][name] = ent
     # ---- K sweep: time = fixed + K * slope at M = 256, N = B * 512 ----
     M, T = KSWEEP["M"], KSWEEP["T"]
@@ -133,17 +146,19 @@ def main():
         x1 = torch.randn(B, Kc, T, device="cuda", generator=g)
         w = (rng.standard_normal((M, Kc, 1)) / np.sqrt(Kc)).astype(np.float32)
         _, ms_f, cs_f = run("f32", x1, None, w, 1, 0, 64064642, 0, args.iters)
-        _, ms_b, cs_b = run("bf3", x1, None, w, 1, 0, 64064642, 6, args.iters)
-        sweep["points"].append({"K": Kc, "f32_us": ms_f * 1e3, "bf3_us": ms_b * 1e3, "f32_cfg": cs_f, "bf3_cfg": cs_b})
-        print(f"K sweep K={Kc:5d}: f32 {ms_f * 1e3:7.1f} us   bf3 {ms_b * 1e3:7.1f} us", flush=True)
+        _, ms_b, cs_b = run("bf3", x1, None, w, 1, 0, 64064642, 0, args.iters, 0)
+        _, ms_h, cs_h = run("bf3", x1, None, w, 1, 0, 64064642, 0, args.iters, 1)
+        sweep["points"].append({"K": Kc, "f32_us": ms_f * 1e3, "bf3_us": ms_b * 1e3, "f16_us": ms_h * 1e3, "f32_cfg": cs_f, "bf3_cfg": cs_b, "f16_cfg": cs_h})
+        print(f"K sweep K={Kc:5d}: f32 {ms_f * 1e3:7.1f} us   bf3 {ms_b * 1e3:7.1f} us   f16 {ms_h * 1e3:7.1f} us", flush=True)
     p0, p1 = sweep["points"][0], sweep["points"][-1]
     dK = p1["K"] - p0["K"]
     fl_per_k = 2.0 * B * T * M
-    for k in ("f32", "bf3"):
+    for k in ("f32", "bf3", "f16"):
         slope_us = (p1[k + "_us"] - p0[k + "_us"]) / dK
         sweep[k + "_kloop_tflops"] = fl_per_k / (slope_us * 1e-6) / 1e12
         sweep[k + "_fixed_us"] = p0[k + "_us"] - slope_us * p0["K"]
     sweep["kloop_speedup"] = sweep["bf3_kloop_tflops"] / sweep["f32_kloop_tflops"]
+    sweep["f16_kloop_speedup"] = sweep["f16_kloop_tflops"] / sweep["f32_kloop_tflops"]
     res["k_sweep"] = sweep
     res["gates"] = {
         "error_le_2x_exact_f32_everywhere": all(s["error_ratio_max"] <= 2.0 and s["error_ratio_rms"] <= 2.0 for s in res["shapes"].values()),
@@ -151,6 +166,11 @@ def main():
         "worst_error_ratio_max": max(s["error_ratio_max"] for s in res["shapes"].values()),
         "worst_error_ratio_rms": max(s["error_ratio_rms"] for s in res["shapes"].values()),
         "min_launch_speedup": min(s["speedup_launch"] for s in res["shapes"].values()),
+        "f16_error_le_2x_exact_f32_everywhere": all(s["f16_error_ratio_max"] <= 2.0 and s["f16_error_ratio_rms"] <= 2.0 for s in res["shapes"].values()),
+        "f16_kloop_speedup_ge_1p5": sweep["f16_kloop_speedup"] >= 1.5,
+        "f16_worst_error_ratio_max": max(s["f16_error_ratio_max"] for s in res["shapes"].values()),
+        "f16_worst_error_ratio_rms": max(s["f16_error_ratio_rms"] for s in res["shapes"].values()),
+        "f16_min_launch_speedup": min(s["f16_speedup_launch"] for s in res["shapes"].values()),
     }
     print(json.dumps(res["gates"]), json.dumps({k: v for k, v in sweep.items() if k != "points"}))
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
