@@ -37,6 +37,13 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (same table); the split-bf16 path spends 6 bf16 products per fp32 product
 PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_SPLIT_F16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0   # fp16 MFMA = the bf16 rate; the fp16-pair path spends 3 products per fp32 product
+SPLIT_MODES = {
+    "split_bf16": {"dtype": "f32-equivalent (3xbf16 operands, 6 products, f32 accumulate)", "peak": PEAK_SPLIT_BF16_TFLOPS,
+                   "peak_note": "2.5 PFLOP/s dense bf16 / 6 bf16 products per fp32 product"},
+    "split_f16": {"dtype": "2xfp16 operands (22 significand bits, weights pre-scaled per layer), 3 products, f32 accumulate", "peak": PEAK_SPLIT_F16_TFLOPS,
+                  "peak_note": "2.5 PFLOP/s dense fp16 / 3 fp16 products per fp32 product"},
+}
 PEAK_HBM_TBS = 8.0               # HBM3E spec peak (same table; ~6.3 TB/s achievable)
 FRAME_SEC = 512 / 44100.0        # one mel frame = hop 512 @ 44.1 kHz (reference configs/config.yaml:3,12)
 UNET_GFLOP_PER_UTT_FWD = 40.98   # SURVEY.md 8d (T=512, M=80), algorithmic
@@ -340,11 +347,13 @@ def run_job(args, rank, world, dev, model=None, voc=None, dist=None, sync=None, 
     return res
 
 
-def split_bf16_leg(args, model, make_inputs):
-    """configs[1] again with every convolution / linear layer of the UNet as an fp32-equivalent split-bf16 GEMM (csrc/conv_bf3.hip: three
-    bf16 terms per fp32 operand, six bf16 products per fp32 product, fp32 accumulate).  Same parity suite, same tolerances
-    (tests/test_gpu_model.py runs every whole-path test in both modes); error study: profiles/r03_split_bf16_probe.json.  Reported next
-    to the exact-fp32 `value`, never as it."""
+def split_leg(args, model, make_inputs, mode):
+    """configs[1] again with every convolution / linear layer of the UNet as a split-operand GEMM on the 16-bit matrix pipe
+    (csrc/conv_bf3.hip, csrc/k8b3.h).  mode "split_bf16": three bf16 terms per fp32 operand (lossless), six products; "split_f16": two fp16
+    terms (22 bits; per-layer weight scale), three products; fp32 accumulate in both.  Same parity suite, same tolerances
+    (tests/test_gpu_model.py runs every whole-path test in all modes); error study: profiles/r03_split_probe_bf16x3_f16x2.json.  Reported
+    next to the exact-fp32 `value`, never as it."""
+    info = SPLIT_MODES[mode]
     unet = model.decoder.denoise_fn
     units, spk = make_inputs(args.batch, args.frames)
     sync = torch.cuda.synchronize
@@ -364,9 +373,9 @@ def split_bf16_leg(args, model, make_inputs):
             torch.randn = real
         return keep["mel"].clone()
     try:
-        y32, y16 = seeded("f32"), seeded("split_bf16")
+        y32, y16 = seeded("f32"), seeded(mode)
         rel = float((y16 - y32).abs().max() / y32.abs().max())
-        step(); sync()                                          # (mode is split_bf16 from here on)
+        step(); sync()                                          # (the split mode stays on from here)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -380,15 +389,15 @@ def split_bf16_leg(args, model, make_inputs):
         conv_tf, _ = conv_family_rate(prof)
         fps = args.batch * args.frames / dt
         return {
-            "workload": f"configs[1] with split-bf16 GEMMs: batch={args.batch}x{args.frames} frames, {args.nfe}-step {args.method}",
-            "dtype": "f32-equivalent (3xbf16 operands, 6 products, f32 accumulate)",
+            "workload": f"configs[1] with {mode} GEMMs: batch={args.batch}x{args.frames} frames, {args.nfe}-step {args.method}",
+            "dtype": info["dtype"],
             "ms_per_step": 1e3 * dt, "mel_frames_per_sec": fps, "x_realtime": fps * FRAME_SEC,
             "unet_algorithmic_tflops": UNET_GFLOP_PER_UTT_FWD * (args.frames / 512.0) * args.batch * args.nfe * 1e9 / dt / 1e12,
             "max_rel_diff_vs_exact_f32_same_xT": rel,
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_SPLIT_BF16_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
-                         "frac": ach / PEAK_SPLIT_BF16_TFLOPS, "peak_note": "2.5 PFLOP/s dense bf16 / 6 bf16 products per fp32 product",
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": info["peak"], "unit": "TFLOP/s (fp32-equivalent)",
+                         "frac": ach / info["peak"], "peak_note": info["peak_note"],
                          "launches": dom["count"], "avg_launch_us": 1e3 * dom["ms"] / dom["count"], "gflop_per_launch": dom["flops"] / dom["count"] / 1e9,
-                         "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / PEAK_SPLIT_BF16_TFLOPS,
+                         "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / info["peak"],
                          "all_conv_gemm_vs_f32_mfma_peak": conv_tf / PEAK_F32_MFMA_TFLOPS, "launches_per_step": roof["launches_per_step"]},
             "kernel_breakdown_ms": breakdown,
         }
@@ -403,7 +412,8 @@ def extra_legs(args, dev, model, make_inputs):
     T = args.frames
     sync = torch.cuda.synchronize
     extra = {}
-    extra["split_bf16"] = split_bf16_leg(args, model, make_inputs)
+    for mode in SPLIT_MODES:
+        extra[mode] = split_leg(args, model, make_inputs, mode)
     units, spk = make_inputs(args.batch, T)
 
     def timeit(fn, n):

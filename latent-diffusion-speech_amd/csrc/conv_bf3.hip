@@ -633,7 +633,7 @@ static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
 
 // tile shape / K-step / ring depth of one launch.  As in conv_dma the choice is made from per-utterance sizes at the nominal
 // per-GPU batch (16), never from the actual batch: an utterance's result is bit-identical for any batch split.
-static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst) {
+static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst, int fmt = FMT_BF16X3) {
     constexpr long long kNominalBatch = 16;
     auto blocks = [&](int bm_, int bn_) -> long long { return (a.Mp % bm_) ? -1 : (long long)(a.Mp / bm_) * ((a.To + bn_ - 1) / bn_) * kNominalBatch; };
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
@@ -647,7 +647,8 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     if (a.stride == 2 || a.ups) { bm = 64; bn = 64; bk = 16; nst = 3; return; }
     if (a.epi == EPI_GEGLU) {
         bm = 128;
-        if (a.To > 64) { bn = 128; bk = 16; nst = 3; }
+        if (a.To > 64 && fmt == FMT_F16X2 && k32) { bn = 128; bk = 32; nst = 2; }      // 64 KB of fp16 stages: two workgroups per CU
+        else if (a.To > 64) { bn = 128; bk = 16; nst = 3; }
         else { bn = 64; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
         return;
     }
@@ -728,7 +729,7 @@ static hipError_t split_dispatch(const DmaConvArgs& a, int cfg, int nprod, hipSt
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 32 || a.B <= 0 || a.To <= 0 || a.pad < 0 || a.pad > 1 || a.voc) return hipErrorInvalidValue;
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     int bm, bn, bk, nst;
-    bf3_pick(a, cfg, bm, bn, bk, nst);
+    bf3_pick(a, cfg, bm, bn, bk, nst, FMT);
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     if ((bk == 64 && !k64) || (bk == 32 && !k32)) return hipErrorInvalidValue;
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
