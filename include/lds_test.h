@@ -74,6 +74,8 @@ int lds_bench_dconv_split(const lds_dconv_test* a, float* out, int B, int iters,
 int lds_test_split_roundtrip(const float* x, float* out, int B, int C, int T, int fmt, void* stream);
 int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                             const float* beta, const float* scale_shift, int silu, float* out, int B, int fmt, void* stream);
+/* tuning only (tools/tune_split_rules.py): bit mask of alternative tile rules of the split-GEMM launcher, 0 = the shipped rules */
+int lds_debug_set_split_rule(int rule);
 /* plain [B,C,T] -> K8B3 -> plain: must return the input bit for bit (the three-term split is lossless) */
 int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream);
 /* GroupNorm(+scale/shift)(+SiLU) through the K8B3 streaming pass (statistics from gn_partials_bf3) */

@@ -633,7 +633,12 @@ static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
 
 // tile shape / K-step / ring depth of one launch.  As in conv_dma the choice is made from per-utterance sizes at the nominal
 // per-GPU batch (16), never from the actual batch: an utterance's result is bit-identical for any batch split.
+// tuning knob (tools/tune_split_rules.py through lds_debug_set_split_rule): bit mask of alternative tile rules, 0 = the shipped rules
+static std::atomic<int> g_split_rule{0};
+void conv_bf3_set_debug_rule(int r) { g_split_rule.store(r); }
+
 static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst, int fmt = FMT_BF16X3) {
+    const int rule = g_split_rule.load(std::memory_order_relaxed);
     constexpr long long kNominalBatch = 16;
     auto blocks = [&](int bm_, int bn_) -> long long { return (a.Mp % bm_) ? -1 : (long long)(a.Mp / bm_) * ((a.To + bn_ - 1) / bn_) * kNominalBatch; };
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
@@ -647,7 +652,8 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     if (a.stride == 2 || a.ups) { bm = 64; bn = 64; bk = 16; nst = 3; return; }
     if (a.epi == EPI_GEGLU) {
         bm = 128;
-        if (a.To > 64 && fmt == FMT_F16X2 && k32) { bn = 128; bk = 32; nst = 2; }      // 64 KB of fp16 stages: two workgroups per CU
+        if (a.To > 64 && fmt == FMT_F16X2 && (rule & 16)) { bn = 128; bk = 16; nst = 4; }
+        else if (a.To > 64 && fmt == FMT_F16X2 && k32) { bn = 128; bk = 32; nst = 2; }      // 64 KB of fp16 stages: two workgroups per CU
         else if (a.To > 64) { bn = 128; bk = 16; nst = 3; }
         else { bn = 64; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
         return;
@@ -657,13 +663,15 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     const bool small = k32 && (b64 <= 256 || (b64 < 512 && b64 % 256));
     if (a.KT == 3) {
         if (small) { bm = 32; bn = 64; bk = 32; nst = 2; }
+        else if ((rule & 4) && k32) { bm = 64; bn = 64; bk = 32; nst = 2; }
         else if (blocks(64, 128) >= 256 && a.To >= 128) { bm = 64; bn = 128; bk = 16; nst = 2; }
         else { bm = 64; bn = 64; bk = 16; nst = 3; }
         return;
     }
     // (in the model, where operands arrive cold, the split tiles are bound by the number of sequential DMA round trips: the deepest K-step)
-    if (small) { bm = 32; bn = 64; bk = k64 ? 64 : 32; nst = 2; }
-    else if (k32 && blocks(128, 64) >= 512) { bm = 128; bn = 64; bk = 32; nst = 2; }
+    if (small) { bm = 32; bn = 64; bk = (k64 && !(rule & 8)) ? 64 : 32; nst = 2; }
+    else if (k32 && blocks(128, 64) >= 512 && !(rule & 1)) { bm = 128; bn = 64; bk = 32; nst = 2; }
+    else if (k64 && (rule & 2)) { bm = 64; bn = 64; bk = 64; nst = 2; }
     else if (k32) { bm = 64; bn = 64; bk = 32; nst = 3; }
     else { bm = 64; bn = 64; bk = 16; nst = 3; }
 }

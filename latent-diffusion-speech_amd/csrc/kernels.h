@@ -117,6 +117,7 @@ hipError_t launch_conv_bf3(const DmaConvArgs& a, int cfg, int nprod, int fmt, hi
 hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, int fmt, hipStream_t s);
 bool conv_bf3_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1);
 const char* conv_bf3_last_config();
+void conv_bf3_set_debug_rule(int r);      // tuning only (lds_debug_set_split_rule)
 // split-plane helpers (k8b3_ops.hip): plain [B][C][T] <-> K8B3 / K8H2 (channels [c_off, c_off + C) of a tensor with Ctot channels); fmt as above
 hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, int fmt = 0);
 hipError_t launch_from_k8b3(const void* in, float* out, int B, int C, int T, hipStream_t s, int fmt = 0);

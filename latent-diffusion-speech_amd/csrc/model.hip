@@ -2118,3 +2118,8 @@ extern "C" int lds_test_gn_apply_split(const float* x1, const float* x2, int C1,
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
 }
+
+extern "C" int lds_debug_set_split_rule(int rule) {
+    conv_bf3_set_debug_rule(rule);
+    return LDS_OK;
+}
