@@ -57,6 +57,8 @@ int lds_test_voc_step(const float* x, const float* w1, const float* b1, const fl
                       const float* acc, float div, float* out, float* out_act, int B, void* stream);
 /* qkv dev [B,3C,T] -> out dev [B,C,T]; softmax(QK^T/sqrt(C/heads))V per head */
 int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
+/* the same with both products on the fp16 matrix pipe, operands split in registers into two fp16 terms (the split-fp16 GEMM mode's attention) */
+int lds_test_attention_f16math(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
 int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
                             float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
                             float in_slope, void* stream);

@@ -24,6 +24,29 @@ namespace lds {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int att_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 att_f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 variant (the split-fp16 GEMM mode, k8b3.h FMT_F16X2): QK^T and P.V on v_mfma_f32_32x32x16_f16 with every fp32 operand split in
+// registers into two fp16 terms (a = a1 + a2, 22 significand bits) and three products per tile (a2 b1 + a1 b2 + a1 b1).  The eight k
+// values of a lane's fragment are two 16-byte entries as they already lie in LDS / registers: (K4P blocks 2t, 2t+1 of row h) for the
+// head-dim reduction, (key quads 4s+h, 4s+2+h) for the key reduction -- which is exactly the order in which the probabilities sit in
+// the score accumulators (registers 8s .. 8s+7), so P feeds the second product from registers as before.
+static __device__ __forceinline__ void att_split8(const f32x4 e0, const f32x4 e1, att_u32x4& p1, att_u32x4& p2) {
+    unsigned a[4], b[4];
+    k8h_split_pair(e0[0], e0[1], a[0], b[0]);
+    k8h_split_pair(e0[2], e0[3], a[1], b[1]);
+    k8h_split_pair(e1[0], e1[1], a[2], b[2]);
+    k8h_split_pair(e1[2], e1[3], a[3], b[3]);
+    p1 = att_u32x4{a[0], a[1], a[2], a[3]};
+    p2 = att_u32x4{b[0], b[1], b[2], b[3]};
+}
+static __device__ __forceinline__ f32x16 att_mfma3(const att_u32x4 a1, const att_u32x4 a2, const att_u32x4 b1, const att_u32x4 b2, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(att_f16x8, a2), __builtin_bit_cast(att_f16x8, b1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(att_f16x8, a1), __builtin_bit_cast(att_f16x8, b2), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(att_f16x8, a1), __builtin_bit_cast(att_f16x8, b1), c, 0, 0, 0);
+    return c;
+}
 
 template <int D, int NW, int NST, int KS = 1>
 struct AttCfg {
@@ -71,7 +94,7 @@ static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc
 
 // KS = 2 (short sequences): the workgroup covers (NW/2)*32 queries and its two wave groups each take one 32-key half of every
 // staged tile, so twice as many waves share the work; the partial (max, sum, output) triples meet through LDS at the end.
-template <int D, int NW, int NST, int KS>
+template <int D, int NW, int NST, int KS, bool F16>
 __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ out,
                                                                 int C, int T, float scale2, int out_bf3) {
     using Cfg = AttCfg<D, NW, NST, KS>;
@@ -114,6 +137,11 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     for (int t = 0; t < NST - 1 && t < nt; ++t) att_issue_tile<D, NW, KPW, VPW>(rk, rv, koff, voff, wave, t, smem + t * STAGE);
 #pragma unroll
     for (int kq = 0; kq < DQ; ++kq) qv[kq] *= scale2;
+    att_u32x4 qh1[F16 ? DQ / 2 : 1], qh2[F16 ? DQ / 2 : 1];      // F16: the query fragments, split once
+    if constexpr (F16) {
+#pragma unroll
+        for (int t = 0; t < DQ / 2; ++t) att_split8(qv[2 * t], qv[2 * t + 1], qh1[t], qh2[t]);
+    }
 
     f32x16 o[DT];
 #pragma unroll
@@ -145,10 +173,19 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            if constexpr (F16) {
 #pragma unroll
-            for (int kq = 0; kq < DQ; ++kq)
+                for (int t = 0; t < DQ / 2; ++t) {
+                    att_u32x4 k1, k2;
+                    att_split8(ka[2 * t], ka[2 * t + 1], k1, k2);
+                    s = att_mfma3(k1, k2, qh1[t], qh2[t], s);
+                }
+            } else {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kq][jj], qv[kq][jj], s, 0, 0, 0);
+                for (int kq = 0; kq < DQ; ++kq)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kq][jj], qv[kq][jj], s, 0, 0, 0);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -192,12 +229,26 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
                     const f32x2 t = f32x2{o[i][r], o[i][r + 1]} * aa;
                     o[i][r] = t[0]; o[i][r + 1] = t[1];
                 }
+            if constexpr (F16) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int ss = 0; ss < 2; ++ss) {
+                    att_u32x4 p1, p2;
+                    att_split8(f32x4{s[8 * ss], s[8 * ss + 1], s[8 * ss + 2], s[8 * ss + 3]}, f32x4{s[8 * ss + 4], s[8 * ss + 5], s[8 * ss + 6], s[8 * ss + 7]}, p1, p2);
 #pragma unroll
-                for (int i = 0; i < DT; ++i)
+                    for (int i = 0; i < DT; ++i) {
+                        att_u32x4 v1, v2;
+                        att_split8(va[2 * ss][i], va[2 * ss + 1][i], v1, v2);
+                        o[i] = att_mfma3(v1, v2, p1, p2, o[i]);
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g][i][e], s[4 * g + e], o[i], 0, 0, 0);
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < DT; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g][i][e], s[4 * g + e], o[i], 0, 0, 0);
+            }
         }
         sc = (sc + 1 == NST) ? 0 : sc + 1;
         sn = (sn + 1 == NST) ? 0 : sn + 1;
@@ -278,10 +329,10 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     }
 }
 
-template <int D, int NW, int NST, int KS>
+template <int D, int NW, int NST, int KS, bool F16>
 static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, int out_bf3, hipStream_t s) {
     using Cfg = AttCfg<D, NW, NST, KS>;
-    auto kern = attention_k4p_kernel<D, NW, NST, KS>;
+    auto kern = attention_k4p_kernel<D, NW, NST, KS, F16>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
@@ -294,7 +345,7 @@ static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B
     return hipGetLastError();
 }
 
-template <int D>
+template <int D, bool F16>
 static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, hipStream_t s) {
     const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
     constexpr int NST = (D == 64) ? 2 : 3;
@@ -302,26 +353,39 @@ static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B,
     const long long hb = (long long)heads * 16;
     // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
     // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
-    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
-    if (T > 32) return launch_cfg<D, 4, NST, 2>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
-    return launch_cfg<D, 1, 2, 1>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    if (T > 32) return launch_cfg<D, 4, NST, 2, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    return launch_cfg<D, 1, 2, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
 }
 
-static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, hipStream_t s) {
+// math_f16: the two products on the fp16 matrix pipe with operands split in registers (the split-fp16 GEMM mode); else exact fp32
+static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, bool math_f16, hipStream_t s) {
     if (C % heads) return hipErrorInvalidValue;
-    ProfScope ps(s, "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
+    ProfScope ps(s, math_f16 ? "attention_f16" : "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
+    if (math_f16) {
+        switch (C / heads) {
+            case 32: return launch_dk<32, true>(qk, vt, out, B, C, T, heads, out_bf3, s);
+            case 48: return launch_dk<48, true>(qk, vt, out, B, C, T, heads, out_bf3, s);
+            case 64: return launch_dk<64, true>(qk, vt, out, B, C, T, heads, out_bf3, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (C / heads) {
-        case 32: return launch_dk<32>(qk, vt, out, B, C, T, heads, out_bf3, s);
-        case 48: return launch_dk<48>(qk, vt, out, B, C, T, heads, out_bf3, s);
-        case 64: return launch_dk<64>(qk, vt, out, B, C, T, heads, out_bf3, s);
+        case 32: return launch_dk<32, false>(qk, vt, out, B, C, T, heads, out_bf3, s);
+        case 48: return launch_dk<48, false>(qk, vt, out, B, C, T, heads, out_bf3, s);
+        case 64: return launch_dk<64, false>(qk, vt, out, B, C, T, heads, out_bf3, s);
         default: return hipErrorInvalidValue;
     }
 }
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
-    return attention_any(qk, vt, out, B, C, T, heads, 0, s);
+    return attention_any(qk, vt, out, B, C, T, heads, 0, false, s);
 }
 hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt) {
-    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, s);
+    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, s);
+}
+// test entry: K4P fp32 in and out, the products on the fp16 pipe
+hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
+    return attention_any(qk, vt, out, B, C, T, heads, 0, true, s);
 }
 
 }  // namespace lds

@@ -652,8 +652,9 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     if (a.stride == 2 || a.ups) { bm = 64; bn = 64; bk = 16; nst = 3; return; }
     if (a.epi == EPI_GEGLU) {
         bm = 128;
+        // (fp16 planes: BK 32 x 2 stages wins back to back on hot operands, 33.9 vs 36.4 us at 256 -> 2048 @ 512, and loses inside the model,
+        //  53 vs 40 us at 384 -> 3072 @ 256: three co-resident workgroups of 16-deep stages hide the cold first tiles better)
         if (a.To > 64 && fmt == FMT_F16X2 && (rule & 16)) { bn = 128; bk = 16; nst = 4; }
-        else if (a.To > 64 && fmt == FMT_F16X2 && k32) { bn = 128; bk = 32; nst = 2; }      // 64 KB of fp16 stages: two workgroups per CU
         else if (a.To > 64) { bn = 128; bk = 16; nst = 3; }
         else { bn = 64; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
         return;

@@ -249,7 +249,10 @@ def test_layernorm_chain_k4p(C, Co, T, B):
 # B * heads * ceil(T/128) >= 256 selects 128-query workgroups, T <= 32 single-wave ones, the rest 64-query ones
 @pytest.mark.parametrize("C,T,B", [(256, 64, 2), (256, 512, 1), (384, 256, 1), (384, 100, 2), (512, 128, 2), (512, 37, 1), (256, 130, 1),
                                    (256, 512, 8), (384, 256, 16), (512, 128, 32), (256, 20, 2), (384, 32, 1)])
-def test_attention_k4p(C, T, B):
+@pytest.mark.parametrize("math", ["f32", "f16x2"])
+def test_attention_k4p(C, T, B, math):
+    """math "f16x2": the same kernel with Q K^T and P V on the fp16 matrix pipe, operands split in registers into two fp16 terms (the
+    attention of the split-fp16 GEMM mode) -- same tolerance"""
     from lds import native
     heads = 8
     d = C // heads
@@ -259,7 +262,8 @@ def test_attention_k4p(C, T, B):
         qkv[:, C:2 * C, 100] *= 10.0          # a dominating key late in the sequence forces the online-softmax rescale
     out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
     dq = dev(qkv)
-    native.check(native.lib().lds_test_attention_k4p(ct.c_void_p(dq.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, heads, stream()))
+    fn = native.lib().lds_test_attention_k4p if math == "f32" else native.lib().lds_test_attention_f16math
+    native.check(fn(ct.c_void_p(dq.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, heads, stream()))
     torch.cuda.synchronize()
     q, k, v = [qkv[:, i * C:(i + 1) * C].reshape(B, heads, d, T).astype(np.float64) for i in range(3)]
     s = np.einsum("bhdq,bhdk->bhqk", q, k) / np.sqrt(d)
