@@ -212,3 +212,25 @@ def test_gn_apply_bf3(C1, C2, T, silu, ss, fmt):
     if silu:
         ref = unet1d.silu(ref)
     assert relmax(out.cpu().numpy(), ref) < 1e-5, relmax(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e3])
+def test_split_formats_vs_activation_scale(scale):
+    """What each format promises when a whole activation tensor lives at another scale (fp64 reference): bf16x3 is lossless, so its error
+    does not depend on the scale; fp16x2 keeps fp32-like relative accuracy from ~0.1 up to 65504 and degrades below (second term
+    subnormal under 2^-3: absolute floor 2^-25) -- the documented precondition of the split-fp16 mode."""
+    B, C, T, Co = 2, 256, 128, 128
+    x = (U("sc.x", (B, C, T), -2, 2) * np.float32(scale)).astype(np.float32)
+    w = (U("sc.w", (Co, C, 1)) / np.float32(16.0)).astype(np.float32)
+    ref = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64))
+    rms = float(np.sqrt((ref ** 2).mean()))
+
+    def err(out):
+        return float(np.sqrt(((out - ref) ** 2).mean())) / rms
+    e_b = err(run_dconv_bf3(x, w, fmt=0))
+    e_h = err(run_dconv_bf3(x, w, fmt=1))
+    assert e_b < 1e-6, e_b                                   # the same fp32-level error at every scale
+    if scale >= 1.0:
+        assert e_h < 1e-6, e_h
+    else:
+        assert 1e-6 < e_h < 2e-4, e_h                        # the floor shows: ~2^-25 / 1e-3 per operand

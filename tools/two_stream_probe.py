@@ -14,9 +14,13 @@ from lds import init_weights  # noqa: E402
 
 B, T = 16, 512
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+MODE = sys.argv[2] if len(sys.argv) > 2 else "f32"      # f32 | split_bf16 | split_f16
 units = torch.from_numpy(init_weights.uniform("bench.units", (B, T, 1280), 1, -1.7, 1.7)).cuda()
 spk = torch.ones(B, 1, dtype=torch.int64, device="cuda")
 mods = [Unit2Mel(1280, 323, 80).to("cuda").eval() for _ in range(NS)]
+for m_ in mods:
+    m_.decoder.denoise_fn.set_gemm_mode(MODE)
+print("GEMM mode", MODE, flush=True)
 streams = [torch.cuda.Stream() for _ in range(NS)]
 h = B // NS
 
