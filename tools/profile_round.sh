@@ -19,5 +19,10 @@ python3 tools/summarize_pmc.py $(find $out/fetch -name "*counter_collection.csv"
 echo "[4/4] MFMA counters" && rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv \
     -d $out/mfma -o m -- python3 bench.py $pmc > /dev/null 2> $out/mfma.err || exit 1
 python3 tools/summarize_mfma.py $(find $out/mfma -name "*counter_collection.csv" | head -1) > $out/mfma_util.json || exit 1
+if [ -n "$2" ]; then      # optional: the same kernel trace for one sampler run in a split GEMM mode (tools/shape_breakdown.py warms up, then 10 NFE)
+  echo "[+] kernel trace, mode $2" && rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$2 -o ks -- python3 tools/shape_breakdown.py 16 --mode $2 > $out/shape_$2.txt 2> $out/ks_$2.err || exit 1
+  cp $(find $out/ks_$2 -name "*kernel_stats.csv" | head -1) $out/kernel_stats_$2.csv
+  rm -rf $out/ks_$2
+fi
 rm -rf $out/ks $out/fetch $out/write $out/mfma      # raw traces are large; the summaries are what is kept
 ls -la $out
