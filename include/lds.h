@@ -197,6 +197,16 @@ int lds_prof_summary(char* buf, size_t cap);
 int lds_unet_set_gemm_mode(lds_unet* u, int mode);
 int lds_unet_get_gemm_mode(const lds_unet* u);
 
+/* ---- latency mode (off by default): the one-sentence caller (reference 22_infer_tts.py:100-114 synthesises one utterance per call) ----
+ * By default every tile / split choice is made at the nominal per-GPU batch of 16, so that an utterance's result is bit-identical
+ * alone, inside any batch and for any shard count -- at the price that one utterance occupies 1/16 of the chip.  With the mode on the
+ * choices follow the ACTUAL batch: smaller tiles, and for deep reductions a cluster of up to 16 workgroups per output tile, each
+ * reducing a share of the K range and the last one to arrive summing the partial tiles in a fixed order (deterministic; csrc/conv_dma.hip
+ * cluster_join).  Same tolerances against the reference; results are NOT bit-identical with the default mode's.  The workspace grows by
+ * 16 MB (lds_unet_workspace_bytes / lds_sampler_workspace_bytes report it).  Applies to every GEMM mode. */
+int lds_unet_set_latency_mode(lds_unet* u, int on);
+int lds_unet_get_latency_mode(const lds_unet* u);
+
 #ifdef __cplusplus
 }
 #endif

@@ -346,11 +346,12 @@ static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B
 }
 
 template <int D, bool F16>
-static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, hipStream_t s) {
+static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, int tile_batch, hipStream_t s) {
     const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
     constexpr int NST = (D == 64) ? 2 : 3;
     // judged at the nominal per-GPU batch (16): the choice fixes the summation order, which must not depend on the batch size
-    const long long hb = (long long)heads * 16;
+    // (tile_batch > 0: the latency mode judges at the actual batch, kernels.h)
+    const long long hb = (long long)heads * (tile_batch > 0 ? tile_batch : 16);
     // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
     // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
     if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
@@ -359,33 +360,33 @@ static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B,
 }
 
 // math_f16: the two products on the fp16 matrix pipe with operands split in registers (the split-fp16 GEMM mode); else exact fp32
-static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, bool math_f16, hipStream_t s) {
+static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, bool math_f16, int tile_batch, hipStream_t s) {
     if (C % heads) return hipErrorInvalidValue;
     ProfScope ps(s, math_f16 ? "attention_f16" : "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
     if (math_f16) {
         switch (C / heads) {
-            case 32: return launch_dk<32, true>(qk, vt, out, B, C, T, heads, out_bf3, s);
-            case 48: return launch_dk<48, true>(qk, vt, out, B, C, T, heads, out_bf3, s);
-            case 64: return launch_dk<64, true>(qk, vt, out, B, C, T, heads, out_bf3, s);
+            case 32: return launch_dk<32, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
+            case 48: return launch_dk<48, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
+            case 64: return launch_dk<64, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
             default: return hipErrorInvalidValue;
         }
     }
     switch (C / heads) {
-        case 32: return launch_dk<32, false>(qk, vt, out, B, C, T, heads, out_bf3, s);
-        case 48: return launch_dk<48, false>(qk, vt, out, B, C, T, heads, out_bf3, s);
-        case 64: return launch_dk<64, false>(qk, vt, out, B, C, T, heads, out_bf3, s);
+        case 32: return launch_dk<32, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
+        case 48: return launch_dk<48, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
+        case 64: return launch_dk<64, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
         default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
-    return attention_any(qk, vt, out, B, C, T, heads, 0, false, s);
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch) {
+    return attention_any(qk, vt, out, B, C, T, heads, 0, false, tile_batch, s);
 }
-hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt) {
-    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, s);
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt, int tile_batch) {
+    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, tile_batch, s);
 }
 // test entry: K4P fp32 in and out, the products on the fp16 pipe
 hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
-    return attention_any(qk, vt, out, B, C, T, heads, 0, true, s);
+    return attention_any(qk, vt, out, B, C, T, heads, 0, true, 0, s);
 }
 
 }  // namespace lds

@@ -639,7 +639,7 @@ void conv_bf3_set_debug_rule(int r) { g_split_rule.store(r); }
 
 static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, int& nst, int fmt = FMT_BF16X3) {
     const int rule = g_split_rule.load(std::memory_order_relaxed);
-    constexpr long long kNominalBatch = 16;
+    const long long kNominalBatch = a.tile_batch > 0 ? a.tile_batch : 16;      // (latency mode: the actual batch, kernels.h)
     auto blocks = [&](int bm_, int bn_) -> long long { return (a.Mp % bm_) ? -1 : (long long)(a.Mp / bm_) * ((a.To + bn_ - 1) / bn_) * kNominalBatch; };
     const bool k32 = (a.Ci % 32 == 0) && (a.C1 % 32 == 0), k64 = (a.Ci % 64 == 0) && (a.C1 % 64 == 0);
     if (cfg) {

@@ -100,6 +100,7 @@ struct DmaKernel {
     const DmaConvArgs& p;
     float* smem;
     int lane, wave, c, h, wm, wn, ks, b, m0, t0;
+    int ksp, kc0, ctile;      // cluster split-K (DmaConvArgs::ksplit): this workgroup's share index, its first K-step, its tile's linear index
     int kofs_a, kofs_b;       // split-K: float offsets of this wave's half of the staged k rows (weights / activations)
     int woff[WPW];            // per-lane byte offsets of this wave's weight chunks (loop invariant)
     int xoff[NXI];            // per-lane byte offsets of this wave's activation chunks inside a source slab
@@ -138,7 +139,10 @@ struct DmaKernel {
         const int tb = L / nMb;
         const int nN = gx / nMb;
         const int nb = tb % nN;
-        b = tb / nN;
+        const int by = tb / nN, S = p.ksplit > 1 ? p.ksplit : 1;      // grid.y = B * S
+        b = by / S; ksp = by - b * S;
+        kc0 = ksp * (p.Ci / BK / S);
+        ctile = (b * nN + nb) * nMb + mb;
         m0 = mb * BM; t0 = nb * BN;
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
@@ -234,7 +238,7 @@ struct DmaKernel {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kc + NST < nk) issue_tile(kc + NST, cur);
+        if (kc + NST < nk) issue_tile(kc0 + kc + NST, cur);
     }
     template <int g>
     __device__ __forceinline__ void kstep(float* cur, const float* nxt, int kc, int nk) {
@@ -324,9 +328,9 @@ struct DmaKernel {
 
     __device__ __forceinline__ void mainloop() {
         static_assert(G % NB == 0 && NB - 1 <= G, "ring slots must keep their phase across K-steps");
-        const int nk = p.Ci / BK;
+        const int nk = p.Ci / BK / (p.ksplit > 1 ? p.ksplit : 1);      // this workgroup's K-steps: kc0 .. kc0 + nk - 1
         if constexpr (EARLY) early_loads();
-        for (int t = 0; t < NST && t < nk; ++t) issue_tile(t, smem + t * STAGE);
+        for (int t = 0; t < NST && t < nk; ++t) issue_tile(kc0 + t, smem + t * STAGE);
         if (p.ln_part) ln_columns();
         wait_younger<NST - 1>((nk - 1 < NST - 1) ? nk - 1 : NST - 1);      // tile 0 landed (this wave's share)
         __builtin_amdgcn_s_barrier();
@@ -595,10 +599,67 @@ struct DmaKernel {
         return true;
     }
 
+    // Cluster split-K (latency mode, DmaConvArgs::ksplit = S > 1): S workgroups share one output tile, each reducing 1/S of the K
+    // range.  Every wave writes its partial accumulators to kpart and counts itself in on its own counter; the wave that arrives
+    // last reads all S partials back in the fixed order s = 0 .. S-1 (its own included: the sum does not depend on the order of
+    // arrival) and runs the epilogue, the others leave.  No workgroup ever waits for another one.  Partials and counters travel
+    // as agent-scope accesses (sc1: write-through stores, L2-coherent loads), the counter add follows the wave's last store
+    // acknowledgement; the last wave puts the counter back to zero for the next launch.
+    __device__ __forceinline__ bool cluster_join() {
+        const int S = p.ksplit;
+        if constexpr (NACC == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[0][i][j] += acc[1][i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[1][i][j][r] = 0.f;
+                }
+        }
+        const int slot = ctile * 4 + wave;
+        float* mine = p.kpart + ((long long)slot * S + ksp) * (TM * TN * 1024) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[0][i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(p.kcount + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != (unsigned)(S - 1)) return false;
+        if (lane == 0) __hip_atomic_store(p.kcount + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* all = p.kpart + (long long)slot * S * (TM * TN * 1024) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][i][j][r] = __hip_atomic_load(all + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 1; q < S; ++q) {
+            const float* pq = all + (long long)q * (TM * TN * 1024);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] += __hip_atomic_load(pq + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
+    }
+
     __device__ __forceinline__ void epilogue() {
         const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
         if constexpr (SPLIT) {
             if (!join_halves()) return;
+        }
+        if constexpr (TM * TN == 1 && !VOC) {      // (the launcher asks for a cluster split on single-block waves only)
+            if (p.ksplit > 1) {
+                if (!cluster_join()) return;
+            }
         }
         finalize(geglu);
         const int ni = geglu ? 1 : TM;
@@ -699,14 +760,17 @@ template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL
 static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
     using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>;
     const int nN = (a.To + BN - 1) / BN;
-    dim3 grid((a.Mp / BM) * nN, a.B);
+    const int S = a.ksplit > 1 ? a.ksplit : 1;
+    if (S > 1 && (Cfg::TM * Cfg::TN != 1 || VOC || (a.Ci / BK) % S)) return hipErrorInvalidValue;
+    dim3 grid((a.Mp / BM) * nN, a.B * S);
     auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    if (!VOC) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x, grid.y, Cfg::LDS_BYTES);
+    if (!VOC && S > 1) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d KS%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, S, grid.x, grid.y, Cfg::LDS_BYTES);
+    else if (!VOC) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x, grid.y, Cfg::LDS_BYTES);
     else snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d D%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, DIL, grid.x, grid.y, Cfg::LDS_BYTES);
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, a);      // bench.py's roofline leg
@@ -722,7 +786,8 @@ static void dma_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     // The tile shape fixes the order of the K reduction, so it must not depend on the batch size: an utterance's result is then
     // bit-identical for any batch split.  Grid sizes are therefore judged at the nominal per-GPU batch of
     // BASELINE.json (16 utterances), whatever a.B is.
-    constexpr long long kNominalBatch = 16;
+    // (a.tile_batch > 0: the opt-in latency mode judges them at the actual batch instead, kernels.h)
+    const long long kNominalBatch = a.tile_batch > 0 ? a.tile_batch : 16;
     auto blocks = [&](int bm, int bn) -> long long { return (a.Mp % bm) ? -1 : (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * kNominalBatch; };
     if (cfg) {
         bm = cfg / 1000000; bn = (cfg / 1000) % 1000; bk = (cfg / 10) % 100; nst = cfg % 10;
@@ -779,18 +844,34 @@ static void dma_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
     }
 }
 
+// Latency mode: how many workgroups share one output tile's K range (1 = no cluster split).  Doubled while the grid stays within
+// ~1.25 workgroups per CU, the K-steps divide evenly and every share keeps >= min_steps of them.
+static int cluster_split(const DmaConvArgs& a, int bm, int bn, int nk, int nk2, int min_steps) {
+    if (a.tile_batch <= 0 || !a.kpart || !a.kcount || a.voc || bm * bn > 64 * 64) return 1;
+    const long long tiles = (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B;
+    if (tiles * 4 > a.kcount_cap) return 1;
+    int S = 1;
+    while (S < 16 && tiles * S * 2 <= 320 && nk % (S * 2) == 0 && nk / (S * 2) >= min_steps && (nk2 == 0 || (nk2 % (S * 2) == 0)) &&
+           tiles * 4 * (S * 2) * 1024 <= a.kpart_cap)
+        S *= 2;
+    return S;
+}
+
 template <int BM, int BN, int BK3, int BK1, int NST>
 static hipError_t launch_pair_cfg(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
     using Cfg = PairCfg<BM, BN, BK3, BK1, NST>;
     const int nN = (a1.To + BN - 1) / BN;
-    dim3 grid((a1.Mp / BM) * nN, a1.B);
+    const int S = a1.ksplit > 1 ? a1.ksplit : 1;
+    if (S > 1 && (Cfg::C1::TM * Cfg::C1::TN != 1 || a3.ksplit != a1.ksplit || (a3.Ci / BK3) % S || (a1.Ci / BK1) % S)) return hipErrorInvalidValue;
+    dim3 grid((a1.Mp / BM) * nN, a1.B * S);
     auto kern = conv_dma_pair_kernel<BM, BN, BK3, BK1, NST>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, grid.x, grid.y, Cfg::LDS_BYTES);
+    if (S > 1) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d KS%d grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, S, grid.x, grid.y, Cfg::LDS_BYTES);
+    else snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT3+1 S1 U0 BK%d+%d NST%d grid %ux%u lds %zu", BM, BN, BK3, BK1, NST, grid.x, grid.y, Cfg::LDS_BYTES);
     DmaPairArgs pp{a3, a1};
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, pp);
@@ -816,8 +897,14 @@ static int pair_variant(const DmaConvArgs& a3, const DmaConvArgs& a1) {
 }
 bool conv_dma_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1) { return pair_variant(a3, a1) != 0; }
 
-hipError_t launch_conv_dma_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
-    switch (pair_variant(a3, a1)) {
+hipError_t launch_conv_dma_pair(const DmaConvArgs& a3_, const DmaConvArgs& a1_, hipStream_t s) {
+    DmaConvArgs a3 = a3_, a1 = a1_;
+    const int pv = pair_variant(a3, a1);
+    if (pv) {
+        const int bm = pv >> 16, bn = (pv >> 8) & 255, bk1 = pv & 255;
+        a3.ksplit = a1.ksplit = cluster_split(a1, bm, bn, a3.Ci / 32, a1.Ci / bk1, 1);
+    }
+    switch (pv) {
         case (32 << 16) | (64 << 8) | 64: return launch_pair_cfg<32, 64, 32, 64, 2>(a3, a1, s);
         case (32 << 16) | (64 << 8) | 32: return launch_pair_cfg<32, 64, 32, 32, 2>(a3, a1, s);
         case (64 << 16) | (64 << 8) | 64: return launch_pair_cfg<64, 64, 32, 64, 2>(a3, a1, s);
@@ -827,7 +914,9 @@ hipError_t launch_conv_dma_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hi
 }
 
 // cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto)
-hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
+hipError_t launch_conv_dma(const DmaConvArgs& a_, int cfg, hipStream_t s) {
+    DmaConvArgs a = a_;
+    a.ksplit = 1;
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 64 || a.B <= 0 || a.To <= 0 || a.xpad < 1 || a.opad < 1 || a.pad < 0 || a.pad > a.xpad) return hipErrorInvalidValue;
     if (a.voc) {
         // vocoder resblock convolutions (k 3 / 7 / 11, dilation 1 / 3 / 5; LeakyReLU / running-sum epilogues): one 64 x 128 tile shape,
@@ -859,6 +948,7 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s) {
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     if (a.Mp % bm) return hipErrorInvalidValue;
     if ((bk == 64 && !k64) || (bk == 32 && !k32)) bk = 16;
+    if (cfg == 0) a.ksplit = cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const int tk = bm * 1000 + bn;
     if (key == 110) {

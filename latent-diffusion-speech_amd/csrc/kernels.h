@@ -95,6 +95,16 @@ struct DmaConvArgs {
     // in fp32 K4P instead (q / k rows for the attention kernel)
     int out_f32;
     float acc_scale;                    // != 0: the accumulators are multiplied by it first (fp16-plane weights are stored times a power of two)
+    // Batch size the tile / split choice is judged at.  0 = the nominal per-GPU batch (16): the choice then never depends on the actual
+    // batch and an utterance's result is bit-identical for any batch split.  > 0 (lds_unet_set_latency_mode): the actual batch, so that
+    // one or two utterances spread over the chip -- same tolerances against the oracle, not bit-identical with batched results.
+    int tile_batch;
+    // Cluster split-K (latency mode only; conv_dma.hip cluster_join): ksplit = S > 1 workgroups share an output tile, each reducing 1/S
+    // of the K-steps; kpart = scratch for the partial tiles (tiles x 4 waves x S x 1024 floats), kcount = one zeroed counter per
+    // (tile, wave), left zeroed.  The launchers choose S (conv_dma_cluster_split) when tile_batch > 0 and kpart / kcount are given.
+    int ksplit;
+    float* kpart; unsigned* kcount;
+    long long kpart_cap; int kcount_cap;      // capacities (floats / counters)
 };
 // cfg: 0 = auto, else BM*1000000 + BN*1000 + BK*10 + NST
 hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
@@ -157,10 +167,11 @@ hipError_t launch_k4p_zero_pads(float* x, int B, int C, int T, int pad, hipStrea
 hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
 // self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v in the VT layout
 // [B][heads][ceil(T/4)][D][4] (key tail zeroed); out K4P [B][C][T]
-hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s);
+// tile_batch: as DmaConvArgs::tile_batch (0 = nominal batch of 16)
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0);
 // the same with the output written as a K8B3 tensor (split-bf16 path: the output feeds the to_out projection)
 hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s);
-hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0);
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0, int tile_batch = 0);
 
 // ---------------------------------------------------------------------------------------------
 // Small dense layers with N = batch columns (time embedding path)

@@ -448,8 +448,26 @@ struct DOpt {
     int cfg = 0;
     int out_f32 = 0;      // split-bf16 path: the K4P-range output channels stay fp32 K4P (q / k for the attention kernel)
 };
+// Batch size the launchers judge their tile / split choices at while a UNet call of this thread is running: 0 = the nominal batch (the
+// default: results do not depend on the batch split), the actual batch in latency mode (lds_unet_set_latency_mode).
+static thread_local int tl_tile_batch = 0;
+// ... and the scratch of the latency mode's cluster split-K (kernels.h DmaConvArgs::ksplit): partial tiles + arrival counters
+constexpr long long kClusterPartFloats = 4ll << 20;      // 16 MB: 320 workgroups x 4 waves x 1024 floats = 1.3 M floats are ever in use
+constexpr int kClusterCounters = 4096;
+static thread_local float* tl_kpart = nullptr;
+static thread_local unsigned* tl_kcount = nullptr;
+struct TileBatchScope {
+    int prev; float* pp; unsigned* pc;
+    explicit TileBatchScope(int tb, float* kpart = nullptr, unsigned* kcount = nullptr) : prev(tl_tile_batch), pp(tl_kpart), pc(tl_kcount) {
+        tl_tile_batch = tb; tl_kpart = tb ? kpart : nullptr; tl_kcount = tb ? kcount : nullptr;
+    }
+    ~TileBatchScope() { tl_tile_batch = prev; tl_kpart = pp; tl_kcount = pc; }
+};
+
 static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, DmaConvArgs& a) {
     memset(&a, 0, sizeof(a));
+    a.tile_batch = tl_tile_batch;
+    a.kpart = tl_kpart; a.kcount = tl_kcount; a.kpart_cap = kClusterPartFloats; a.kcount_cap = kClusterCounters;
     if (C1 + C2 != W.Ci) return fail(LDS_EINVAL, "dconv: input channels %d+%d != %d", C1, C2, W.Ci);
     a.x1 = x1; a.x2 = x2 ? x2 : x1; a.C1 = C1; a.C2 = C2; a.Tsrc = Tsrc;
     a.w = W.w; a.bias = W.bias; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
@@ -658,6 +676,7 @@ struct lds_unet {
     int max_ci = 0;
     int gemm_mode = LDS_GEMM_F32;      // LDS_GEMM_SPLIT_BF16 / LDS_GEMM_SPLIT_F16: every conv / linear through conv_bf3 (lds_unet_set_gemm_mode)
     bool split_packed[2] = {false, false};
+    int latency_mode = 0;              // 1: tile / split choices from the actual batch (lds_unet_set_latency_mode)
 };
 
 static float* up_vec(Owner& o, const float* p, int64_t n) {
@@ -952,6 +971,12 @@ extern "C" int lds_unet_set_gemm_mode(lds_unet* u, int mode) {
     return LDS_OK;
 }
 extern "C" int lds_unet_get_gemm_mode(const lds_unet* u) { return u ? u->gemm_mode : LDS_EINVAL; }
+extern "C" int lds_unet_set_latency_mode(lds_unet* u, int on) {
+    if (!u || (on != 0 && on != 1)) return fail(LDS_EINVAL, "bad argument");
+    u->latency_mode = on;
+    return LDS_OK;
+}
+extern "C" int lds_unet_get_latency_mode(const lds_unet* u) { return u ? u->latency_mode : LDS_EINVAL; }
 
 static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
 
@@ -959,6 +984,7 @@ static int down_len(int T) { return (T - 1) / 2 + 1; }  // Conv1d k3 s2 p1
 struct UnetWs {
     float *e1, *emb, *tproj;
     float2* lnp;
+    float* kpart; unsigned* kcount;      // latency mode: cluster split-K scratch (partial tiles, arrival counters)
     float* xin;
     float *xk, *ck, *cinc;      // sampler runs: the sample alone in K4P, the condition alone, conv_in's condition half (+ bias), computed once per run
     std::vector<float*> skips;
@@ -1034,6 +1060,8 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.gno = A.f(B * maxgn);
     w.qk = A.f(B * maxatt * 2); w.v = A.f(B * (maxatt + 2048)); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
     w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2);
+    w.kpart = u->latency_mode ? A.f(kClusterPartFloats) : nullptr;
+    w.kcount = u->latency_mode ? (unsigned*)A.f(kClusterCounters) : nullptr;
     A.f(16384);   // tail slack: ragged last tiles read (masked) entries past a tensor's end
 }
 
@@ -1090,8 +1118,8 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
         oq.out_f32 = bf3 ? 1 : 0;                                          // (split-bf16 mode: q / k / v stay fp32 for the attention kernel)
         LDS_TRY(dconv_any(bf3, t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
-        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1));
-        else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st));
+        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1, tl_tile_batch));
+        else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st, tl_tile_batch));
         DOpt oo;
         oo.res = h; oo.lnpart_out = w.lnp;
         LDS_TRY(dconv_any(bf3, t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
@@ -1122,6 +1150,8 @@ static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_b
     UnetWs w;
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
+    TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
+    if (u->latency_mode) HIP_TRY(launch_fill((float*)w.kcount, 0.f, kClusterCounters, st));      // (bit pattern 0 = counter 0)
     // conv_in is linear in its input channels: the condition's contribution (and the bias) is the same for every evaluation of the run.
     // It is computed here once; an evaluation convolves the 80 sample channels only and adds it as the residual (1008 -> 240 reduction
     // terms per output of conv_in, every NFE).
@@ -1141,6 +1171,9 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     UnetWs w;
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
+    TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
+    // the counters are left at zero by every launch that uses them; a forward starts from zeroed ones whatever the workspace held before
+    if (u->latency_mode && !cond_staged) HIP_TRY(launch_fill((float*)w.kcount, 0.f, kClusterCounters, st));
     const int nb = u->cfg.n_blocks;
     const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch.

@@ -37,6 +37,7 @@ class UNet1DConditionModel(ParamTree):
         self.in_channels, self.out_channels = in_channels, out_channels
         self._native = None
         self._gemm_mode = "f32"
+        self._latency_mode = False
 
     # Any change of the parameters drops the packed copy: .to()/.float() go through _apply; load_state_dict -- called on
     # this module OR on any parent (Unit2Mel / GaussianDiffusion: nn.Module.load_state_dict recurses through the children's
@@ -54,7 +55,18 @@ class UNet1DConditionModel(ParamTree):
             self._native = native.UNet(self.cfg, {k: v for k, v in self.state_dict().items()})
             if self._gemm_mode != "f32":
                 self._native.set_gemm_mode(self._gemm_mode)
+            if self._latency_mode:
+                self._native.set_latency_mode(True)
         return self._native
+
+    def set_latency_mode(self, on):
+        """Opt-in for one or two utterances per call (the reference's 22_infer_tts.py loop): tile shapes and K splits are chosen from
+        the actual batch so that a single utterance spreads over the chip.  Same tolerances against the reference, but not
+        bit-identical with the default mode, whose results never depend on how a batch is split (include/lds.h).  Not part of the
+        reference's API."""
+        self._latency_mode = bool(on)
+        if self._native is not None:
+            self._native.set_latency_mode(self._latency_mode)
 
     def set_gemm_mode(self, mode):
         """"f32" (default): every conv / linear on the exact-fp32 MFMA.  "split_bf16": the same layers as fp32-equivalent split-bf16

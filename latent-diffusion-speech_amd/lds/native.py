@@ -50,7 +50,8 @@ EXPORTS = [
     "lds_unet_forward", "lds_sampler_run", "lds_sampler_workspace_bytes", "lds_embed_create", "lds_embed_destroy",
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_gather_rows", "lds_resample_frames", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_lm_create", "lds_lm_destroy", "lds_lm_workspace_bytes", "lds_lm_encode",
-    "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_unet_set_gemm_mode", "lds_unet_get_gemm_mode"]
+    "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_unet_set_gemm_mode", "lds_unet_get_gemm_mode",
+    "lds_unet_set_latency_mode", "lds_unet_get_latency_mode"]
 # include/lds_test.h: single-op entry points for tests/ and tools/ (not part of the drop-in boundary)
 TEST_EXPORTS = [
     "lds_test_conv", "lds_test_dconv", "lds_bench_dconv", "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p",
@@ -76,6 +77,8 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p]
         L.lds_unet_set_gemm_mode.argtypes = [C.c_void_p, C.c_int]
         L.lds_unet_get_gemm_mode.argtypes = [C.c_void_p]
+        L.lds_unet_set_latency_mode.argtypes = [C.c_void_p, C.c_int]
+        L.lds_unet_get_latency_mode.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -158,6 +161,13 @@ class UNet:
 
     def gemm_mode(self):
         return int(lib().lds_unet_get_gemm_mode(self.h))
+
+    def set_latency_mode(self, on):
+        """Tile / split choices from the actual batch (one or two utterances fill the chip); include/lds.h"""
+        check(lib().lds_unet_set_latency_mode(self.h, 1 if on else 0))
+
+    def latency_mode(self):
+        return int(lib().lds_unet_get_latency_mode(self.h))
 
     def forward(self, x, cond, t):
         import torch

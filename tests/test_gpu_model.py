@@ -338,3 +338,99 @@ def test_parent_load_state_dict_repacks_weights(unit2mel_gpu):
     sd2["denoise_fn.conv_out.bias"] -= 0.5
     m.decoder.load_state_dict(sd2)
     assert torch.allclose(m.decoder.denoise_fn(x, t).sample, e0, atol=1e-5)
+
+
+# ---- latency mode (lds_unet_set_latency_mode): tile shapes and cluster split-K chosen from the ACTUAL batch ----------
+# Same fixtures, same tolerances as the default mode; the oracle results are shared with the tests above (oracle_once).
+@pytest.fixture(scope="module", params=["f32", "split_f16"])
+def unit2mel_latency(request):
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from diffusion.unit2mel import Unit2Mel
+    m = Unit2Mel(1280, 323, 80)
+    m.to("cuda").eval()
+    m.decoder.denoise_fn.set_gemm_mode(request.param)
+    m.decoder.denoise_fn.set_latency_mode(True)
+    assert m.decoder.denoise_fn.native().latency_mode() == 1
+    return m
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_latency_unet_forward_vs_reference(golden, unit2mel_latency, case, record_margin):
+    g = golden("unet_fwd.npz")
+    unet = unit2mel_latency.decoder.denoise_fn
+    t = g[f"{case}_t"]
+    tt = dev(t) if t.dtype != np.int64 else torch.from_numpy(t).cuda()
+    y = unet(dev(g[f"{case}_x"]), tt).sample.cpu().numpy()
+    assert np.isfinite(y).all()
+    record_margin(relmax(y, g[f"{case}_y"]), 2e-5)
+
+
+def test_latency_unet_full_size_vs_oracle(unit2mel_latency, unet_weights, record_margin):
+    """one and two T = 512 utterances (the sizes the mode is for: every deep reduction runs as a workgroup cluster) vs the oracle;
+    a repeated call is bit-identical (the partial tiles are summed in a fixed order, whatever the order of arrival)"""
+    from lds import init_weights
+    from oracle import unet1d
+    cfg, blocks, w = unet_weights
+    unet = unit2mel_latency.decoder.denoise_fn
+    x = init_weights.uniform("full.x", (2, 336, 512), 41, -2, 2)
+    t = np.array([873.25, 40.5], dtype=np.float32)
+    ref = oracle_once("full0", lambda: unet1d.unet_forward(w, cfg, blocks, x[:1], t[:1]))
+    ref1 = oracle_once("full1", lambda: unet1d.unet_forward(w, cfg, blocks, x[1:], t[1:]))
+    one = unet(dev(x[:1]), dev(t[:1])).sample
+    record_margin(relmax(one.cpu().numpy(), ref), 2e-5, "B1")
+    for _ in range(3):
+        assert torch.equal(unet(dev(x[:1]), dev(t[:1])).sample, one)
+    two = unet(dev(x), dev(t)).sample.cpu().numpy()
+    record_margin(relmax(two[:1], ref), 2e-5, "B2.utt0")
+    record_margin(relmax(two[1:], ref1), 2e-5, "B2.utt1")
+
+
+@pytest.mark.parametrize("B,T", [(1, 77), (2, 1000), (1, 2050), (5, 512)])
+def test_latency_unet_other_sizes(unit2mel_latency, B, T, record_margin):
+    """ragged lengths and other batches: the latency mode against the default mode of the same model (both within 2e-5 of the oracle at
+    the sizes checked above; here 4e-5 between them)"""
+    from lds import init_weights
+    unet = unit2mel_latency.decoder.denoise_fn
+    x = dev(init_weights.uniform(f"sz.{B}.{T}", (B, 336, T), 33, -2, 2))
+    t = dev(np.full((B,), 250.25, dtype=np.float32))
+    lat = unet(x, t).sample
+    unet.set_latency_mode(False)
+    try:
+        base = unet(x, t).sample
+    finally:
+        unet.set_latency_mode(True)
+    assert torch.isfinite(lat).all()
+    record_margin(relmax(lat.cpu().numpy(), base.cpu().numpy()), 4e-5)
+
+
+@pytest.mark.parametrize("name,method,speedup,k_step,B", [
+    ("dpm50", "dpm-solver", 20, 1000, 2), ("unipc20", "unipc", 50, 1000, 2), ("ddpm12", None, 1, 12, 2)])
+def test_latency_sampler_vs_reference(golden, unit2mel_latency, monkeypatch, name, method, speedup, k_step, B, record_margin):
+    g = golden("sampler.npz")
+    gd = unit2mel_latency.decoder
+    draws = [dev(n) for n in g[name + "_noise"]]
+    real = torch.randn
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: draws.pop(0) if draws else real(*a, **k))
+    gd.k_step = k_step
+    try:
+        y = gd(dev(g["cond"][:B]), infer=True, infer_speedup=speedup, method=method).cpu().numpy()
+    finally:
+        gd.k_step = 1000
+    assert not draws
+    record_margin(relmax(y, g[name + "_y"]), 1e-4)
+
+
+def test_latency_sampler_bench_size_vs_oracle(unit2mel_latency, unet_weights, monkeypatch, record_margin):
+    """the caller the mode is for: one 512-frame utterance, 10-NFE DPM-Solver++, against oracle.solvers over the oracle UNet"""
+    from lds import init_weights
+    from oracle import schedule, solvers, unit2mel as o_u2m
+    cfg, blocks, w = unet_weights
+    gd = unit2mel_latency.decoder
+    T = 512
+    cond = init_weights.uniform("bench512.cond", (1, T, 256), 51, -1, 1)
+    xT = init_weights.uniform("bench512.xT", (1, 1, 80, T), 52, -1.7, 1.7)
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: dev(xT))
+    y = gd(dev(cond), infer=True, infer_speedup=100, method="dpm-solver").cpu().numpy()
+    f = o_u2m.make_eps_fn(w, cfg, blocks, np.ascontiguousarray(cond.transpose(0, 2, 1)))
+    ref = oracle_once(("bench512", "dpm-solver"), lambda: solvers.sample(f, schedule.diffusion_buffers(), xT[:, 0], "dpm-solver", 100))
+    record_margin(relmax(y, np.ascontiguousarray(ref.transpose(0, 2, 1))), 1e-4)

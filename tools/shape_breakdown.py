@@ -39,9 +39,11 @@ def main():
     ap.add_argument("B", nargs="?", type=int, default=16)
     ap.add_argument("--mode", default="f32")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--latency", action="store_true", help="latency mode (tile / split choices from the actual batch)")
     a = ap.parse_args()
     B, T = a.B, 512
     m = Unit2Mel(1280, 323, 80).to("cuda").eval()
+    m.decoder.denoise_fn.set_latency_mode(a.latency)
     units = torch.from_numpy(init_weights.uniform("bench.units", (B, T, 1280), 1, -1.7, 1.7)).cuda()
     spk = torch.ones(B, 1, dtype=torch.int64, device="cuda")
     modes = ["f32", "split_bf16"] if a.mode == "both" else [a.mode]
