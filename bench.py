@@ -472,16 +472,30 @@ def extra_legs(args, dev, model, make_inputs):
 
     def one():
         return model(u1, None, spk_id=s1, infer=True, infer_speedup=1000 // args.nfe, method=args.method)
-    dt = timeit(one, 3)
-    prof = NativeProfiler().run(one)
-    conv_tf, _ = conv_family_rate(prof)
-    extra["b1_latency"] = {
-        "workload": f"1 utterance x {T} frames, {args.nfe}-step {args.method} (latency of the 22_infer_tts.py caller)",
-        "ms_per_utterance": 1e3 * dt, "mel_frames_per_sec": T / dt, "x_realtime": T / dt * FRAME_SEC,
-        "unet_algorithmic_tflops": UNET_GFLOP_PER_UTT_FWD * (T / 512.0) * args.nfe * 1e9 / dt / 1e12,
-        "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
-        "launches_per_step": int(sum(r["count"] for r in prof)),
-    }
+    unet = model.decoder.denoise_fn
+
+    def b1_leg():
+        dt = timeit(one, 3)
+        prof = NativeProfiler().run(one)
+        conv_tf, _ = conv_family_rate(prof)
+        return {"ms_per_utterance": 1e3 * dt, "mel_frames_per_sec": T / dt, "x_realtime": T / dt * FRAME_SEC,
+                "unet_algorithmic_tflops": UNET_GFLOP_PER_UTT_FWD * (T / 512.0) * args.nfe * 1e9 / dt / 1e12,
+                "all_conv_gemm_tflops": conv_tf, "all_conv_gemm_frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
+                "launches_per_step": int(sum(r["count"] for r in prof))}
+    extra["b1_latency"] = {"workload": f"1 utterance x {T} frames, {args.nfe}-step {args.method} (latency of the 22_infer_tts.py caller)",
+                           "mode": "default: tile choices at the nominal batch of 16, bit-identical with batched results", **b1_leg()}
+    # the opt-in latency mode (lds_unet_set_latency_mode): tiles and cluster split-K from the actual batch; same tolerances vs the
+    # oracle (tests/test_gpu_model.py::test_latency_*), not bit-identical with the default mode
+    unet.set_latency_mode(True)
+    try:
+        extra["b1_latency_mode"] = {"workload": extra["b1_latency"]["workload"], "mode": "latency mode, exact fp32", **b1_leg()}
+        unet.set_gemm_mode("split_f16")
+        leg = b1_leg()
+        leg.pop("all_conv_gemm_frac")
+        extra["b1_latency_mode_split_f16"] = {"workload": extra["b1_latency"]["workload"], "mode": "latency mode, split-fp16 GEMMs", **leg}
+    finally:
+        unet.set_gemm_mode("f32")
+        unet.set_latency_mode(False)
     # ---- configs[5], one GPU's share (8 of 64 utterances): phones -> RoFormer generate (512 tokens) -> units -> mel -> wav ----
     sys.path.insert(0, ROOT)
     import infer_tts
@@ -527,10 +541,16 @@ def extra_legs(args, dev, model, make_inputs):
     dt_lm1 = timeit(lm_one, 2)
     dt1 = timeit(full_one, 2)
     assert tuple(keep["tok1"].shape) == (1, T) and bool(torch.isfinite(keep["wav1"]).all())
+    unet.set_latency_mode(True)
+    try:
+        dt1_lat = timeit(full_one, 2)
+    finally:
+        unet.set_latency_mode(False)
     extra["b1_full_tts_latency"] = {
         "workload": f"1 utterance: {Lp} phones -> {T} sampled tokens -> {args.nfe}-step {args.method} -> {T * 512} samples (22_infer_tts.py, one sentence)",
         "ms_per_utterance": 1e3 * dt1, "audio_seconds": T * FRAME_SEC, "x_realtime": T * FRAME_SEC / dt1, "rtf": dt1 / (T * FRAME_SEC),
         "lm_ms": 1e3 * dt_lm1, "lm_us_per_decode_step": 1e6 * dt_lm1 / T,
+        "latency_mode_ms_per_utterance": 1e3 * dt1_lat, "latency_mode_x_realtime": T * FRAME_SEC / dt1_lat,
     }
     return extra
 

@@ -59,6 +59,8 @@ int lds_test_voc_step(const float* x, const float* w1, const float* b1, const fl
 int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
 /* the same with both products on the fp16 matrix pipe, operands split in registers into two fp16 terms (the split-fp16 GEMM mode's attention) */
 int lds_test_attention_f16math(const float* qkv, float* out, int B, int C, int T, int heads, void* stream);
+/* the latency mode's configuration choice (judged at the actual batch: 32-query workgroups whose four waves share the keys); f16math 0 / 1 */
+int lds_test_attention_latency(const float* qkv, float* out, int B, int C, int T, int heads, int f16math, void* stream);
 int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, const float* bias,
                             float* out, int B, int Ci, int Co, int T, int K, int stride, int pad,
                             float in_slope, void* stream);

@@ -60,6 +60,7 @@ struct AttCfg {
     // + slack: with D = 48 the second 32-row operand tile reads up to 15 entries past the last V tile (rows never stored)
     static constexpr size_t LDS_BYTES = (size_t)NST * STAGE * sizeof(float) + 256;
     static_assert(KROWS % NW == 0 && VCH % NW == 0, "tile must split evenly over the waves");
+    static_assert(KS == 1 || (size_t)(KS - 1) * (NW / KS) * (2 + 16 * DT) * 64 * sizeof(float) <= LDS_BYTES, "the join's partials reuse the K/V stages");
 };
 
 static __device__ __forceinline__ float max3(float a, float b, float c) {
@@ -150,18 +151,33 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // KS = 4 (latency mode) with the whole sequence resident in the ring: one wait for everything and one barrier, then every wave
+    // runs through its own chunks without meeting the others (a per-tile barrier would make the four waves take turns: chunk j of
+    // tile kt belongs to one wave only)
+    const bool resident = (KS == 4) && nt <= NST - 1;
+    if (resident) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     int sc = 0, sn = NST - 1;
     for (int kt = 0; kt < nt; ++kt) {
-        // this wave's share of tile kt has landed when at most the younger tiles' DMAs are outstanding
-        const int younger = (nt - 1 - kt < NST - 2) ? (nt - 1 - kt) : (NST - 2);
-        att_wait_younger<NST - 2, PER_TILE>(younger);
-        __builtin_amdgcn_s_barrier();              // every wave's share landed; every wave is done with the stage refilled below
-        asm volatile("" ::: "memory");
-        if (kt + NST - 1 < nt) att_issue_tile<D, NW, KPW, VPW>(rk, rv, koff, voff, wave, kt + NST - 1, smem + sn * STAGE);
+        if (!resident) {
+            // this wave's share of tile kt has landed when at most the younger tiles' DMAs are outstanding
+            const int younger = (nt - 1 - kt < NST - 2) ? (nt - 1 - kt) : (NST - 2);
+            att_wait_younger<NST - 2, PER_TILE>(younger);
+            __builtin_amdgcn_s_barrier();              // every wave's share landed; every wave is done with the stage refilled below
+            asm volatile("" ::: "memory");
+            if (kt + NST - 1 < nt) att_issue_tile<D, NW, KPW, VPW>(rk, rv, koff, voff, wave, kt + NST - 1, smem + sn * STAGE);
+        }
         const float* Kc = smem + sc * STAGE;
         const float* Vc = Kc + KB * D;
+        // KS = 1: both 32-key halves of the tile; KS = 2: half ks; KS = 4: half (ks & 1) of every other tile (the 32-key chunks of the
+        // sequence go round-robin over the four waves)
+        const int h0 = (KS == 1) ? 0 : (KS == 2) ? ks : (ks & 1);
+        const int h1 = (KS == 1) ? KB / 32 : (KS == 2 || (kt & 1) == (ks >> 1)) ? h0 + 1 : h0;
 #pragma unroll 1
-        for (int half = (KS == 2 ? ks : 0); half < (KS == 2 ? ks + 1 : KB / 32); ++half) {
+        for (int half = h0; half < h1; ++half) {
             const int kbase = kt * KB + half * 32;
             if (kbase >= T) break;
             // operands are fetched ahead of their use and pinned there: all K operands before the first QK MFMA, all V operands
@@ -253,11 +269,12 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         sc = (sc + 1 == NST) ? 0 : sc + 1;
         sn = (sn + 1 == NST) ? 0 : sn + 1;
     }
-    if constexpr (KS == 2) {
-        // join the two key halves: (m, l, o) of the ks = 1 wave into its ks = 0 partner, fixed order
+    if constexpr (KS >= 2) {
+        // join the key shares: (m, l, o) of the ks >= 1 waves into their ks = 0 partner, fixed order
         __syncthreads();                                   // all waves are done with the K/V stages
-        float* red = smem + qw * (2 + 16 * DT) * 64 + lane;
-        if (ks == 1) {
+        constexpr int RED = (2 + 16 * DT) * 64;            // floats per partial
+        if (ks >= 1) {
+            float* red = smem + ((ks - 1) * NWQ + qw) * RED + lane;
             red[0] = m_run; red[64] = l_run;
 #pragma unroll
             for (int i = 0; i < DT; ++i)
@@ -265,15 +282,20 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
                 for (int r = 0; r < 16; ++r) red[(2 + i * 16 + r) * 64] = o[i][r];
         }
         __syncthreads();
-        if (ks == 1) return;
-        const float m1 = red[0], l1 = red[64];
-        const float m = fmaxf(m_run, m1);
-        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);      // a1 = 0 when the other half saw no key
-        l_run = l_run * a0 + l1 * a1;
+        if (ks >= 1) return;
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+        for (int q = 1; q < KS; ++q) {
+            const float* red = smem + ((q - 1) * NWQ + qw) * RED + lane;
+            const float m1 = red[0], l1 = red[64];
+            const float m = fmaxf(m_run, m1);
+            const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);      // a1 = 0 when the other share saw no key
+            l_run = l_run * a0 + l1 * a1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + red[(2 + i * 16 + r) * 64] * a1;
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + red[(2 + i * 16 + r) * 64] * a1;
+            m_run = m;
+        }
     }
     float l;
     {
@@ -355,6 +377,11 @@ static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B,
     // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
     // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
     if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    // latency mode, few (batch, head) pairs: 32 queries per workgroup, the keys' 32-key chunks round-robin over its four waves
+    // (and a ring deep enough to have every K / V tile of the level's sequence in flight at once: with one workgroup per CU the tiles'
+    //  DMA round trips, ~1 us each when taken two at a time, are what a short launch consists of; 144 / 123 / 128 KB of LDS)
+    constexpr int NSTL = (D == 32) ? 9 : (D == 48) ? 5 : 4;
+    if (tile_batch > 0 && T > 64 && (long long)((T + 63) / 64) * hb < 256) return launch_cfg<D, 4, NSTL, 4, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
     if (T > 32) return launch_cfg<D, 4, NST, 2, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
     return launch_cfg<D, 1, 2, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
 }
@@ -385,8 +412,8 @@ hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* 
     return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, tile_batch, s);
 }
 // test entry: K4P fp32 in and out, the products on the fp16 pipe
-hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s) {
-    return attention_any(qk, vt, out, B, C, T, heads, 0, true, 0, s);
+hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch) {
+    return attention_any(qk, vt, out, B, C, T, heads, 0, true, tile_batch, s);
 }
 
 }  // namespace lds

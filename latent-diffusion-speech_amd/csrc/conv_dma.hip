@@ -656,7 +656,7 @@ struct DmaKernel {
         if constexpr (SPLIT) {
             if (!join_halves()) return;
         }
-        if constexpr (TM * TN == 1 && !VOC) {      // (the launcher asks for a cluster split on single-block waves only)
+        if constexpr (TM * TN <= 2 && !VOC) {      // (the launcher asks for a cluster split on waves of one or two blocks only)
             if (p.ksplit > 1) {
                 if (!cluster_join()) return;
             }
@@ -761,7 +761,7 @@ static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
     using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>;
     const int nN = (a.To + BN - 1) / BN;
     const int S = a.ksplit > 1 ? a.ksplit : 1;
-    if (S > 1 && (Cfg::TM * Cfg::TN != 1 || VOC || (a.Ci / BK) % S)) return hipErrorInvalidValue;
+    if (S > 1 && (Cfg::TM * Cfg::TN > 2 || VOC || (a.Ci / BK) % S)) return hipErrorInvalidValue;
     dim3 grid((a.Mp / BM) * nN, a.B * S);
     auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
@@ -845,14 +845,15 @@ static void dma_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
 }
 
 // Latency mode: how many workgroups share one output tile's K range (1 = no cluster split).  Doubled while the grid stays within
-// ~1.25 workgroups per CU, the K-steps divide evenly and every share keeps >= min_steps of them.
+// one workgroup per CU (a CU with two takes twice as long), the K-steps divide evenly and every share keeps >= min_steps of them.
 static int cluster_split(const DmaConvArgs& a, int bm, int bn, int nk, int nk2, int min_steps) {
-    if (a.tile_batch <= 0 || !a.kpart || !a.kcount || a.voc || bm * bn > 64 * 64) return 1;
+    if (a.tile_batch <= 0 || !a.kpart || !a.kcount || a.voc || bm * bn > 128 * 64) return 1;
+    const int blk = bm * bn > 64 * 64 ? 2 : 1;      // 32 x 32 blocks per wave
     const long long tiles = (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B;
     if (tiles * 4 > a.kcount_cap) return 1;
     int S = 1;
-    while (S < 16 && tiles * S * 2 <= 320 && nk % (S * 2) == 0 && nk / (S * 2) >= min_steps && (nk2 == 0 || (nk2 % (S * 2) == 0)) &&
-           tiles * 4 * (S * 2) * 1024 <= a.kpart_cap)
+    while (S < 16 && tiles * S * 2 <= 256 && nk % (S * 2) == 0 && nk / (S * 2) >= min_steps && (nk2 == 0 || (nk2 % (S * 2) == 0)) &&
+           tiles * 4 * (S * 2) * blk * 1024 <= a.kpart_cap)
         S *= 2;
     return S;
 }

@@ -170,7 +170,7 @@ hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Ti
 // tile_batch: as DmaConvArgs::tile_batch (0 = nominal batch of 16)
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0);
 // the same with the output written as a K8B3 tensor (split-bf16 path: the output feeds the to_out projection)
-hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s);
+hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0);
 hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0, int tile_batch = 0);
 
 // ---------------------------------------------------------------------------------------------

@@ -2071,14 +2071,17 @@ extern "C" int lds_test_voc_step(const float* x, const float* w1, const float* b
     return LDS_OK;
 }
 
-static int attention_test_impl(const float* qkv, float* out, int B, int C, int T, int heads, int f16math, void* stream);
+static int attention_test_impl(const float* qkv, float* out, int B, int C, int T, int heads, int f16math, void* stream, int tile_batch = 0);
 extern "C" int lds_test_attention_k4p(const float* qkv, float* out, int B, int C, int T, int heads, void* stream) {
     return attention_test_impl(qkv, out, B, C, T, heads, 0, stream);
 }
 extern "C" int lds_test_attention_f16math(const float* qkv, float* out, int B, int C, int T, int heads, void* stream) {
     return attention_test_impl(qkv, out, B, C, T, heads, 1, stream);
 }
-static int attention_test_impl(const float* qkv, float* out, int B, int C, int T, int heads, int f16math, void* stream) {
+extern "C" int lds_test_attention_latency(const float* qkv, float* out, int B, int C, int T, int heads, int f16math, void* stream) {
+    return attention_test_impl(qkv, out, B, C, T, heads, f16math, stream, B);      // the latency mode's choice (tile_batch = the actual batch)
+}
+static int attention_test_impl(const float* qkv, float* out, int B, int C, int T, int heads, int f16math, void* stream, int tile_batch) {
     hipStream_t st = (hipStream_t)stream;
     TmpDev tmp;
     float* qkp = tmp.f((size_t)B * 2 * C * T);       // plain [B][2C][T]
@@ -2093,8 +2096,8 @@ static int attention_test_impl(const float* qkv, float* out, int B, int C, int T
     }
     HIP_TRY(launch_to_k4p(qkp, kqk, B, 2 * C, T, 2 * C, 0, st));
     HIP_TRY(launch_plain_to_vt(vpl, vt, B, C, T, C / heads, st));
-    if (f16math) HIP_TRY(launch_attention_k4p_f16math(kqk, vt, ko, B, C, T, heads, st));
-    else HIP_TRY(launch_attention_k4p(kqk, vt, ko, B, C, T, heads, st));
+    if (f16math) HIP_TRY(launch_attention_k4p_f16math(kqk, vt, ko, B, C, T, heads, st, tile_batch));
+    else HIP_TRY(launch_attention_k4p(kqk, vt, ko, B, C, T, heads, st, tile_batch));
     HIP_TRY(launch_from_k4p(ko, out, B, C, T, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;

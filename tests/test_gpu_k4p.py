@@ -249,7 +249,7 @@ def test_layernorm_chain_k4p(C, Co, T, B):
 # B * heads * ceil(T/128) >= 256 selects 128-query workgroups, T <= 32 single-wave ones, the rest 64-query ones
 @pytest.mark.parametrize("C,T,B", [(256, 64, 2), (256, 512, 1), (384, 256, 1), (384, 100, 2), (512, 128, 2), (512, 37, 1), (256, 130, 1),
                                    (256, 512, 8), (384, 256, 16), (512, 128, 32), (256, 20, 2), (384, 32, 1)])
-@pytest.mark.parametrize("math", ["f32", "f16x2"])
+@pytest.mark.parametrize("math", ["f32", "f16x2", "f32-lat", "f16x2-lat"])
 def test_attention_k4p(C, T, B, math):
     """math "f16x2": the same kernel with Q K^T and P V on the fp16 matrix pipe, operands split in registers into two fp16 terms (the
     attention of the split-fp16 GEMM mode) -- same tolerance"""
@@ -262,8 +262,12 @@ def test_attention_k4p(C, T, B, math):
         qkv[:, C:2 * C, 100] *= 10.0          # a dominating key late in the sequence forces the online-softmax rescale
     out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
     dq = dev(qkv)
-    fn = native.lib().lds_test_attention_k4p if math == "f32" else native.lib().lds_test_attention_f16math
-    native.check(fn(ct.c_void_p(dq.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, heads, stream()))
+    if math.endswith("-lat"):      # the latency mode's choice: 32-query workgroups, key chunks round-robin over four waves
+        native.check(native.lib().lds_test_attention_latency(ct.c_void_p(dq.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, heads,
+                                                             1 if math.startswith("f16") else 0, stream()))
+    else:
+        fn = native.lib().lds_test_attention_k4p if math == "f32" else native.lib().lds_test_attention_f16math
+        native.check(fn(ct.c_void_p(dq.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, T, heads, stream()))
     torch.cuda.synchronize()
     q, k, v = [qkv[:, i * C:(i + 1) * C].reshape(B, heads, d, T).astype(np.float64) for i in range(3)]
     s = np.einsum("bhdq,bhdk->bhqk", q, k) / np.sqrt(d)
