@@ -98,6 +98,7 @@ struct Bf3Kernel {
     const DmaConvArgs& p;
     float* smem;
     int lane, wave, c, h, wm, wn, ks, b, m0, t0;
+    int ksp, kc0, ctile;      // cluster split-K (latency mode; conv_dma.hip cluster_join): share index, first K-step, tile index
     int woff[NWI];            // per-lane byte offsets of this wave's weight chunks (loop invariant)
     int xoff[NXI];            // per-lane byte offsets of this wave's activation chunks inside a source slab
     __amdgpu_buffer_rsrc_t rw, rx1, rx2;
@@ -127,7 +128,10 @@ struct Bf3Kernel {
         const int tb = L / nMb;
         const int nN = gx / nMb;
         const int nb = tb % nN;
-        b = tb / nN;
+        const int by = tb / nN, S = p.ksplit > 1 ? p.ksplit : 1;      // grid.y = B * S
+        b = by / S; ksp = by - b * S;
+        kc0 = ksp * (p.Ci / BK / S);
+        ctile = (b * nN + nb) * nMb + mb;
         m0 = mb * BM; t0 = nb * BN;
         constexpr int kOob = 0x40000000;      // beyond every buffer: the range check returns zeros
 #pragma unroll
@@ -242,7 +246,7 @@ struct Bf3Kernel {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kc + NST < nk) issue_tile(kc + NST, cur);
+        if (kc + NST < nk) issue_tile(kc0 + kc + NST, cur);
     }
     // PH: slot phase of this K-step (odd G: the ring's slots swap roles every K-step)
     template <int g, int PH>
@@ -314,9 +318,9 @@ struct Bf3Kernel {
     }
 
     __device__ __forceinline__ void mainloop() {
-        const int nk = p.Ci / BK;
+        const int nk = p.Ci / BK / (p.ksplit > 1 ? p.ksplit : 1);      // this workgroup's K-steps: kc0 .. kc0 + nk - 1
         if constexpr (EARLY) early_loads();
-        for (int t = 0; t < NST && t < nk; ++t) issue_tile(t, smem + t * STAGE);
+        for (int t = 0; t < NST && t < nk; ++t) issue_tile(kc0 + t, smem + t * STAGE);
         if (p.ln_part) ln_columns();
         wait_younger<NST - 1>((nk - 1 < NST - 1) ? nk - 1 : NST - 1);      // tile 0 landed (this wave's share)
         __builtin_amdgcn_s_barrier();
@@ -530,10 +534,52 @@ struct Bf3Kernel {
         return true;
     }
 
+    // cluster split-K of the latency mode: as conv_dma.hip cluster_join (partials summed by the last wave to arrive, fixed order)
+    __device__ __forceinline__ bool cluster_join() {
+        const int S = p.ksplit;
+        const int slot = ctile * 4 + wave;
+        float* mine = p.kpart + ((long long)slot * S + ksp) * (TM * TN * 1024) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(p.kcount + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != (unsigned)(S - 1)) return false;
+        if (lane == 0) __hip_atomic_store(p.kcount + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* all = p.kpart + (long long)slot * S * (TM * TN * 1024) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = __hip_atomic_load(all + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 1; q < S; ++q) {
+            const float* pq = all + (long long)q * (TM * TN * 1024);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += __hip_atomic_load(pq + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
+    }
+
     __device__ __forceinline__ void epilogue() {
         const bool geglu = (p.epi == EPI_GEGLU) && (TM == 2);
         if constexpr (SPLIT) {
             if (!join_halves()) return;
+        }
+        if constexpr (TM * TN <= 2) {
+            if (p.ksplit > 1) {
+                if (!cluster_join()) return;
+            }
         }
         finalize(geglu);
         const int ni = geglu ? 1 : TM;
@@ -616,14 +662,18 @@ template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPR
 static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
     using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>;
     const int nN = (a.To + BN - 1) / BN;
-    dim3 grid((a.Mp / BM) * nN, a.B);
+    const int S = a.ksplit > 1 ? a.ksplit : 1;
+    if (S > 1 && (Cfg::TM * Cfg::TN > 2 || (a.Ci / BK) % S)) return hipErrorInvalidValue;
+    dim3 grid((a.Mp / BM) * nN, a.B * S);
     auto kern = conv_bf3_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, FMT == FMT_F16X2 ? "H" : "P",
+    if (S > 1) snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d KS%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST,
+                        FMT == FMT_F16X2 ? "H" : "P", NPROD, S, grid.x, grid.y, Cfg::LDS_BYTES);
+    else snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, FMT == FMT_F16X2 ? "H" : "P",
              NPROD, grid.x, grid.y, Cfg::LDS_BYTES);
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, a);
@@ -654,7 +704,9 @@ static void bf3_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
         bm = 128;
         // (fp16 planes: BK 32 x 2 stages wins back to back on hot operands, 33.9 vs 36.4 us at 256 -> 2048 @ 512, and loses inside the model,
         //  53 vs 40 us at 384 -> 3072 @ 256: three co-resident workgroups of 16-deep stages hide the cold first tiles better)
-        if (a.To > 64 && fmt == FMT_F16X2 && (rule & 16)) { bn = 128; bk = 16; nst = 4; }
+        // (latency mode, a grid that leaves most of the chip idle: the half-width tile, whose two-block waves may share K in a cluster)
+        if (a.tile_batch > 0 && (long long)(a.Mp / 128) * ((a.To + 127) / 128) * a.tile_batch < 192) { bn = 64; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
+        else if (a.To > 64 && fmt == FMT_F16X2 && (rule & 16)) { bn = 128; bk = 16; nst = 4; }
         else if (a.To > 64) { bn = 128; bk = 16; nst = 3; }
         else { bn = 64; bk = k32 ? 32 : 16; nst = k32 ? 2 : 3; }
         return;
@@ -681,7 +733,9 @@ template <int BM, int BN, int BK3, int BK1, int NST, int FMT>
 static hipError_t launch_bf3_pair_cfg(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
     using Cfg = Bf3PairCfg<BM, BN, BK3, BK1, NST, FMT>;
     const int nN = (a1.To + BN - 1) / BN;
-    dim3 grid((a1.Mp / BM) * nN, a1.B);
+    const int S = a1.ksplit > 1 ? a1.ksplit : 1;
+    if (S > 1 && (BM * BN > 128 * 64 || a3.ksplit != a1.ksplit || (a3.Ci / BK3) % S || (a1.Ci / BK1) % S)) return hipErrorInvalidValue;
+    dim3 grid((a1.Mp / BM) * nN, a1.B * S);
     auto kern = conv_bf3_pair_kernel<BM, BN, BK3, BK1, NST, FMT>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
@@ -716,8 +770,27 @@ static int bf3_pair_variant(const DmaConvArgs& a3, const DmaConvArgs& a1) {
 }
 bool conv_bf3_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1) { return bf3_pair_variant(a3, a1) != 0; }
 
+// latency mode: workgroups per output tile (conv_dma.hip cluster_split)
+static int bf3_cluster_split(const DmaConvArgs& a, int bm, int bn, int nk, int nk2, int min_steps) {
+    if (a.tile_batch <= 0 || !a.kpart || !a.kcount || bm * bn > 128 * 64) return 1;
+    const int blk = bm * bn > 64 * 64 ? 2 : 1;
+    const long long tiles = (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B;
+    if (tiles * 4 > a.kcount_cap) return 1;
+    int S = 1;
+    while (S < 16 && tiles * S * 2 <= 256 && nk % (S * 2) == 0 && nk / (S * 2) >= min_steps && (nk2 == 0 || (nk2 % (S * 2) == 0)) &&
+           tiles * 4 * (S * 2) * blk * 1024 <= a.kpart_cap)
+        S *= 2;
+    return S;
+}
+
 template <int FMT>
-static hipError_t pair_dispatch(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s) {
+static hipError_t pair_dispatch(const DmaConvArgs& a3_, const DmaConvArgs& a1_, hipStream_t s) {
+    DmaConvArgs a3 = a3_, a1 = a1_;
+    {
+        const int v = bf3_pair_variant(a3, a1);
+        const int bm = v == 1 ? 32 : 64, bn = v == 2 ? 128 : 64, bk3 = v == 1 ? 32 : 16;
+        a3.ksplit = a1.ksplit = v ? bf3_cluster_split(a1, bm, bn, a3.Ci / bk3, a1.Ci / 32, 1) : 1;
+    }
     switch (bf3_pair_variant(a3, a1)) {      // the 1x1 half runs BK 32 on the k 3 half's tile
         case 1: return launch_bf3_pair_cfg<32, 64, 32, 32, 2, FMT>(a3, a1, s);
         case 2: return launch_bf3_pair_cfg<64, 128, 16, 32, 2, FMT>(a3, a1, s);
@@ -734,7 +807,9 @@ hipError_t launch_conv_bf3_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, in
 // cfg = BM*1000000 + BN*1000 + BK*10 + NST (0 = auto); nprod = the format's default (bf16x3: 6, fp16x2: 3) or, on the probe's 128 x 128 x BK32
 // tile only, bf16x3: 3 / 9, fp16x2: 4
 template <int FMT>
-static hipError_t split_dispatch(const DmaConvArgs& a, int cfg, int nprod, hipStream_t s) {
+static hipError_t split_dispatch(const DmaConvArgs& a_, int cfg, int nprod, hipStream_t s) {
+    DmaConvArgs a = a_;
+    a.ksplit = 1;
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 32 || a.B <= 0 || a.To <= 0 || a.pad < 0 || a.pad > 1 || a.voc) return hipErrorInvalidValue;
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     int bm, bn, bk, nst;
@@ -743,6 +818,7 @@ static hipError_t split_dispatch(const DmaConvArgs& a, int cfg, int nprod, hipSt
     if ((bk == 64 && !k64) || (bk == 32 && !k32)) return hipErrorInvalidValue;
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     if (a.Mp % bm) return hipErrorInvalidValue;
+    if (cfg == 0) a.ksplit = bf3_cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const int tk = bm * 1000 + bn;
     if (nprod != (FMT == FMT_F16X2 ? 3 : 6)) {

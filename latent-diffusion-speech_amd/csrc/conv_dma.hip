@@ -263,7 +263,7 @@ struct DmaKernel {
     // tiles' DMAs are issued; the partials are fetched eight at a time so the loads overlap instead of forming a chain
     // of dependent round trips.
     __device__ __forceinline__ void ln_columns() {
-        constexpr int CH = 8;
+        constexpr int CH = 16;      // (all partials of the widest level, 512 channels, in one round trip)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = t0 + wn * TN * 32 + j * 32 + c;
