@@ -45,6 +45,11 @@ int lds_test_gn_apply(const float* x1, const float* x2, int C1, int C2, int T, i
                       const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
 /* average time of one streaming-GroupNorm launch on zero-filled tensors (tools/bench_gn.py) */
 int lds_bench_gn_stream(int C1, int C2, int T, int B, int iters, float* ms_out, void* stream);
+/* conv 1x1 (C -> Cm, GroupNorm partials from its epilogue) -> proj(GroupNorm(mid)) (Cm -> Co) as ONE launch with the normalisation folded into the
+ * projection (csrc/kernels.h DmaConvArgs::gnf_part); tile_batch > 0: the latency mode's tile / cluster-split choices at that batch */
+int lds_test_gn_fold_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps, int groups,
+                         const float* w2, const float* bias2, float* mid, float* out, int B, int C, int Cm, int Co, int T, int cfg, int tile_batch,
+                         void* stream);
 /* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
  * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
 int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,
@@ -79,6 +84,8 @@ int lds_test_split_roundtrip(const float* x, float* out, int B, int C, int T, in
 int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                             const float* beta, const float* scale_shift, int silu, float* out, int B, int fmt, void* stream);
 /* tuning only (tools/tune_split_rules.py): bit mask of alternative tile rules of the split-GEMM launcher, 0 = the shipped rules */
+/* 0: the transformer blocks' GroupNorm runs as its own pass instead of folded into proj_in (A/B measurements and tests); default 1 */
+int lds_debug_set_gn_fold(int on);
 int lds_debug_set_split_rule(int rule);
 /* plain [B,C,T] -> K8B3 -> plain: must return the input bit for bit (the three-term split is lossless) */
 int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream);

@@ -20,6 +20,7 @@
 // read NB-1 MFMA groups ahead and runs THROUGH the K-step boundary: the per-tile synchronisation (counted vmcnt for
 // this wave's share of the next tile, one s_barrier, refill of the stage just finished) sits NB-1 groups before the
 // end of a K-step, where the ring starts reading the next tile, so no K-step begins with an exposed LDS latency.
+#include "gn_chan.h"
 #include "k4p.h"
 #include "kernels.h"
 
@@ -90,7 +91,8 @@ struct DmaCfg {
     static_assert(!SPLIT || (BN == 64 && BK % 16 == 0), "split-K tile is 32 x 64");
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
+// GNF: the GroupNorm fold of DmaConvArgs::gnf_part (its own instantiations: the other launches carry none of its registers)
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false, bool GNF = false>
 struct DmaKernel {
     using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>;
     static constexpr int TM = Cfg::TM, TN = Cfg::TN, KR = Cfg::KR, XW = Cfg::XW, WPW = Cfg::WPW, RPW = Cfg::RPW, NXI = Cfg::NXI;
@@ -101,6 +103,9 @@ struct DmaKernel {
     float* smem;
     int lane, wave, c, h, wm, wn, ks, b, m0, t0;
     int ksp, kc0, ctile;      // cluster split-K (DmaConvArgs::ksplit): this workgroup's share index, its first K-step, its tile's linear index
+    float gcg[GNF ? 8 : 1], gkc;      // (threads < BM: the terms of their row's constant, in flight across the first barrier)
+    GnPart gp0, gp1;                  // this wave's two groups' partial statistics, in flight across the first DMAs
+    float gs, gsn, ginv;              // rstd of the group of this wave's share of the current / the next K-step; 1 / (channels per group)
     int kofs_a, kofs_b;       // split-K: float offsets of this wave's half of the staged k rows (weights / activations)
     int woff[WPW];            // per-lane byte offsets of this wave's weight chunks (loop invariant)
     int xoff[NXI];            // per-lane byte offsets of this wave's activation chunks inside a source slab
@@ -214,6 +219,10 @@ struct DmaKernel {
     }
     template <int SLOT>
     __device__ __forceinline__ void mfma_ops() {
+        if constexpr (GNF) {      // GroupNorm fold: the activations of this K-step's group times its rstd (2 packed multiplies per operand entry)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bop[SLOT][j] *= gs;
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -289,6 +298,65 @@ struct DmaKernel {
         }
     }
 
+    // ---- GroupNorm fold (DmaConvArgs::gnf_part) ----
+    // LDS behind the ring: [0, BM) the per-row constants, then 8 x rstd_g and 8 x rstd_g * mean_g of this batch element
+    __device__ __forceinline__ float* gnf_tail() const { return smem + NST * STAGE + BM; }
+    // group of this wave's share of K-step k (of this workgroup's range), clamped to the last one (look-ahead past the end)
+    __device__ __forceinline__ int gnf_group(int k) const {
+        const int pos = (kc0 + k) * BK + ks * (SPLIT ? BK / 2 : BK);
+        const int g = (int)(((float)pos + 0.5f) * ginv);
+        return g < p.gnf_groups ? g : p.gnf_groups - 1;
+    }
+    // kernel start, before the first DMA (so that waiting for them does not wait for the tiles): the requests for this wave's two groups'
+    // partials (wave w takes groups w and w + 4) and for the terms of the row constants
+    __device__ __forceinline__ void gnf_request() {
+        const int G_ = p.gnf_groups, gsz = p.Ci / G_;
+        ginv = 1.0f / (float)gsz;
+        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0);                              // (8 groups at most: wave < G_ or an unused slot)
+        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0);
+        if ((int)threadIdx.x < BM) {
+            const int m = m0 + (int)threadIdx.x;
+            gkc = p.gnf_c2[m];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) gcg[g] = (g < G_) ? p.gnf_cg[g * p.Mp + m] : 0.f;
+        }
+    }
+    // after the first tiles' DMAs are issued, before the first barrier: the statistics into LDS
+    __device__ __forceinline__ void gnf_prepare() {
+        const int G_ = p.gnf_groups, gsz = p.Ci / G_;
+        float* tail = gnf_tail();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int g = wave + 4 * e;
+            float rs = 1.f, rm = 0.f;      // (slots of absent groups: finite, they multiply zeros)
+            if (g < G_) {
+                float mu, var;
+                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var);
+                rs = 1.0f / sqrtf(var + p.gnf_eps); rm = rs * mu;
+            }
+            if (lane == 0) { tail[g] = rs; tail[8 + g] = rm; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the stores are in LDS before this wave passes the barrier (s_barrier alone does not wait)
+    }
+    // after the first barrier: kc[m] = gnf_c2[m] - sum_g rstd_g mean_g gnf_cg[g][m]  (read in finalize, behind further barriers), and the
+    // scale of this wave's first two K-steps
+    __device__ __forceinline__ void gnf_rows() {
+        const float* tail = gnf_tail();
+        if ((int)threadIdx.x < BM) {
+            float kc = gkc;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) kc = fmaf(-tail[8 + g], gcg[g], kc);      // (groups beyond gnf_groups: gcg = 0, tail finite)
+            smem[NST * STAGE + threadIdx.x] = kc;
+        }
+        gs = tail[gnf_group(0)];
+        gsn = tail[gnf_group(1)];
+    }
+    // after K-step k: the next step's scale becomes current, the one after it is requested (its LDS latency hides under the next step)
+    __device__ __forceinline__ void gnf_advance(int k) {
+        gs = gsn;
+        gsn = gnf_tail()[gnf_group(k + 2)];
+    }
+
     // s_waitcnt vmcnt(y * PER_TILE) for a wave-uniform y in [0, Y]: the y younger tiles' DMAs may stay in flight
     template <int Y>
     __device__ __forceinline__ void wait_younger(int y) {
@@ -329,19 +397,24 @@ struct DmaKernel {
     __device__ __forceinline__ void mainloop() {
         static_assert(G % NB == 0 && NB - 1 <= G, "ring slots must keep their phase across K-steps");
         const int nk = p.Ci / BK / (p.ksplit > 1 ? p.ksplit : 1);      // this workgroup's K-steps: kc0 .. kc0 + nk - 1
+        if constexpr (GNF) gnf_request();
         if constexpr (EARLY) early_loads();
         for (int t = 0; t < NST && t < nk; ++t) issue_tile(kc0 + t, smem + t * STAGE);
         if (p.ln_part) ln_columns();
+        if constexpr (GNF) gnf_prepare();
         wait_younger<NST - 1>((nk - 1 < NST - 1) ? nk - 1 : NST - 1);      // tile 0 landed (this wave's share)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (GNF) gnf_rows();
         preload<0, NB - 1>(smem);
         int sc = 0;
         for (int kc = 0; kc < nk; ++kc) {
             const int sn = (sc + 1 == NST) ? 0 : sc + 1;
             kstep<0>(smem + sc * STAGE, smem + sn * STAGE, kc, nk);
             sc = sn;
+            if constexpr (GNF) gnf_advance(kc);
         }
+        if constexpr (GNF) __syncthreads();      // (the row constants are read in finalize: a one-K-step launch has met no barrier since)
     }
 
     // Epilogue, phase 1: accumulators -> output values in place (acc[0]).  All loads of a phase are issued before their
@@ -381,6 +454,16 @@ struct DmaKernel {
                         const float v = acc[0][i][j][r];
                         acc[0][i][j][r] = ln ? lrs[j] * (v - lmu[j] * k1[i][r]) + k2[i][r] : v + k2[i][r];
                     }
+        }
+        if constexpr (GNF) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float kc = smem[NST * STAGE + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[0][i][j][r] += kc;
+                }
         }
         if (geglu) {      // rows of tile 0 are the values, rows of tile 1 the gates (pack_geglu)
 #pragma unroll
@@ -706,11 +789,11 @@ struct DmaKernel {
     }
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false, bool GNF = false>
 // (the polyphase upsampler's scatter epilogue needs more than the 128 registers of 4 workgroups per CU: 2 per CU, no spills)
 __global__ void __launch_bounds__(256, ((VOC && KT == 2) ? 2 : DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>::OCC)) conv_dma_kernel(const DmaConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC> k(p, smem);
+    DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC, GNF> k(p, smem);
     k.setup();
     k.mainloop();
     k.epilogue();
@@ -756,25 +839,28 @@ __global__ void __launch_bounds__(256, (PairCfg<BM, BN, BK3, BK1, NST>::OCC)) co
 static thread_local char g_dcfg[96] = "";
 const char* conv_dma_last_config() { return g_dcfg; }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int DIL = 1, bool VOC = false, bool GNF = false>
 static hipError_t launch_dma_cfg(const DmaConvArgs& a, hipStream_t s) {
     using Cfg = DmaCfg<BM, BN, KT, STRIDE, UPS, BK, NST, DIL>;
+    if (GNF != (a.gnf_part != nullptr)) return hipErrorInvalidValue;
+    const size_t lds_bytes = Cfg::LDS_BYTES + (GNF ? (BM + 32) * sizeof(float) : 0);      // the fold's row constants and group statistics sit behind the ring
     const int nN = (a.To + BN - 1) / BN;
     const int S = a.ksplit > 1 ? a.ksplit : 1;
     if (S > 1 && (Cfg::TM * Cfg::TN > 2 || VOC || (a.Ci / BK) % S)) return hipErrorInvalidValue;
     dim3 grid((a.Mp / BM) * nN, a.B * S);
-    auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC>;
-    if (Cfg::LDS_BYTES > 48 * 1024) {
+    auto kern = conv_dma_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC, GNF>;
+    if (lds_bytes > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    if (!VOC && S > 1) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d KS%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, S, grid.x, grid.y, Cfg::LDS_BYTES);
-    else if (!VOC) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, grid.x, grid.y, Cfg::LDS_BYTES);
+    const char* gtag = GNF ? " GNF" : "";
+    if (!VOC && S > 1) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d KS%d%s grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, S, gtag, grid.x, grid.y, lds_bytes);
+    else if (!VOC) snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d%s grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, gtag, grid.x, grid.y, lds_bytes);
     else snprintf(g_dcfg, sizeof(g_dcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d D%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, DIL, grid.x, grid.y, Cfg::LDS_BYTES);
     hipEvent_t e0, e1;
-    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, a);      // bench.py's roofline leg
-    else hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, e0, e1, 0, a);      // bench.py's roofline leg
+    else hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -949,6 +1035,21 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_, int cfg, hipStream_t s) {
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     if (a.Mp % bm) return hipErrorInvalidValue;
     if ((bk == 64 && !k64) || (bk == 32 && !k32)) bk = 16;
+    if (a.gnf_part) {
+        // GroupNorm fold: a 1x1 convolution over one source whose every wave's share of a K-step lies inside one group
+        if (a.KT != 1 || a.stride != 1 || a.ups || a.C2 != 0 || a.ln_part || a.epi != EPI_NONE || a.bias || !a.gnf_cg || !a.gnf_c2 || a.gnf_groups < 1 ||
+            a.gnf_groups > 8 || a.Ci % a.gnf_groups || (a.Ci / a.gnf_groups) % 16)
+            return hipErrorInvalidValue;
+        const int gsz = a.Ci / a.gnf_groups;
+        if (bm * bn > 128 * 64) bn = 64;
+        while (gsz % (bm == 32 ? bk / 2 : bk)) bk /= 2;      // (a split tile's half K-step of 16 channels divides every group size)
+        if (bm != 32 && bk == 16) nst = 3;
+        if (cfg == 0) a.ksplit = cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
+#define GCASE(BM, BN, BK, NS) if (bm == BM && bn == BN && bk == BK && nst == NS) return launch_dma_cfg<BM, BN, 1, 1, false, BK, NS, 1, false, true>(a, s)
+        GCASE(32, 64, 32, 2); GCASE(32, 64, 64, 2); GCASE(64, 64, 32, 2); GCASE(64, 64, 16, 3); GCASE(128, 64, 32, 2); GCASE(128, 64, 16, 3);
+#undef GCASE
+        return hipErrorInvalidValue;
+    }
     if (cfg == 0) a.ksplit = cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const int tk = bm * 1000 + bn;

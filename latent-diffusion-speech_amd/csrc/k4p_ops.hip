@@ -5,6 +5,7 @@
 // entries with unit stride; the GroupNorm statistics are per-block partials written by the producing convolution's
 // epilogue and combined with Chan's formula in a fixed order, never atomics, so results do not depend on scheduling.
 #include "k4p.h"
+#include "gn_chan.h"
 #include "kernels.h"
 
 #include <hip/hip_ext.h>
@@ -138,10 +139,6 @@ hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, 
 // computes the same from a K4P tensor (stand-alone entry points).  gn_stream_kernel is the only pass over the tensor.
 
 // Wave64 reduction helpers in a fixed order (DPP row shifts + row broadcasts): the result is valid in lane 63.
-template <int CTRL, int ROW_MASK, bool BOUND>
-static __device__ __forceinline__ float dpp_get(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
-}
 static __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v += dpp_get<0x111, 0xf, true>(v);
     v += dpp_get<0x112, 0xf, true>(v);
@@ -151,22 +148,6 @@ static __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v += dpp_get<0x143, 0xc, false>(v);
     return v;
 }
-// Chan's parallel combination of (count, mean, M2); an empty side (count 0) is the identity
-static __device__ __forceinline__ void chan(float& n, float& mean, float& m2, float nb, float mb, float qb) {
-    const float nn = n + nb;
-    const float r = (nn > 0.f) ? __builtin_amdgcn_rcpf(nn) : 0.f;      // counts are small integers: v_rcp_f32 is within 1 ulp
-    const float d = mb - mean;
-    mean += d * (nb * r);
-    m2 += qb + d * d * (n * nb * r);
-    n = nn;
-}
-template <int CTRL, int ROW_MASK, bool BOUND>
-static __device__ __forceinline__ void chan_step(float& n, float& mean, float& m2) {
-    // lanes outside ROW_MASK (and row starts with BOUND) receive zeros = an empty partial
-    const float nb = dpp_get<CTRL, ROW_MASK, BOUND>(n), mb = dpp_get<CTRL, ROW_MASK, BOUND>(mean), qb = dpp_get<CTRL, ROW_MASK, BOUND>(m2);
-    chan(n, mean, m2, nb, mb, qb);
-}
-
 // one wave per (16-channel block, 32-frame block)
 __global__ void __launch_bounds__(64) gn_partials_kernel(const float* __restrict__ x, int C, int T, float2* __restrict__ gp) {
     const int nT = (T + 31) >> 5, kb = blockIdx.x / nT, tb = blockIdx.x - kb * nT, b = blockIdx.y, lane = threadIdx.x;

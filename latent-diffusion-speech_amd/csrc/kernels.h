@@ -79,6 +79,14 @@ struct DmaConvArgs {
     //   y[m,t] = rstd_t * (acc[m,t] - mean_t * ln_c1[m]) + ln_c2[m],  c1 = sum_c W[m,c]*gamma_c,  c2 = sum_c W[m,c]*beta_c + bias[m]
     // mean_t / rstd_t are combined per column from the producer's partials ln_part [B][ln_np][Tsrc]
     const float2* ln_part; int ln_np; float ln_eps; const float* ln_c1; const float* ln_c2;
+    // GroupNorm of the INPUT (affine, no activation: the transformer's `norm` in front of proj_in, reference transformer_1d.py:256-266)
+    // folded into a 1x1 convolution over ONE source (weights pre-multiplied by gamma on the host):
+    //   y[m,t] = sum_g rstd_g * (sum_{c in g} Wg[m,c] x[c,t]) - sum_g rstd_g mean_g gnf_cg[g][m] + gnf_c2[m]
+    //   gnf_cg[g][m] = sum_{c in g} W[m,c] gamma_c,  gnf_c2[m] = sum_c W[m,c] beta_c + bias[m]
+    // The channels of a group are contiguous and every wave's share of a K-step lies inside one group: its activation operands are
+    // multiplied by that group's rstd on their way from LDS to the MFMA (two packed multiplies per four MFMAs); the per-(batch, group)
+    // statistics are combined from the producer's partials gnf_part [B][Ci/16][ceil(Tsrc/32)] (the same ones gn_stream reads) at kernel start.
+    const float2* gnf_part; int gnf_groups; float gnf_eps; const float* gnf_cg; const float* gnf_c2;
     int Cout, To, B;
     // vocoder extensions (HiFi-VAEGAN MRF, reference models.py:161-262); the UNet leaves them at dil 1, xpad = opad = 1, rest 0 / 1.0
     int voc;                            // 1: vocoder kernel family (the fields below are honoured)

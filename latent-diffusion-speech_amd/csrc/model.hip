@@ -340,6 +340,34 @@ static bool pack_ln_fold(Owner& o, const float* w, const float* b, const float* 
     return out.w && c1_out && c2_out;
 }
 
+// GroupNorm (affine, no activation) folded into a following 1x1 convolution (DmaConvArgs::gnf_part): weights pre-multiplied by gamma,
+// cg[g][m] = sum_{c in group g} W[m,c] gamma_c (what the group's mean multiplies) and c2[m] = sum_c W[m,c] beta_c + bias[m]
+static bool pack_gn_fold(Owner& o, const float* w, const float* b, const float* gamma, const float* beta, int Co, int Ci, int groups, ConvW& out,
+                         float*& cg_out, float*& c2_out) {
+    const int Mp = round_mp(Co), gsz = Ci / groups;
+    std::vector<float> p((size_t)Ci * Mp, 0.f), cg((size_t)groups * Mp, 0.f), c2(Mp, 0.f);
+    for (int m = 0; m < Co; ++m) {
+        double s2 = b ? (double)b[m] : 0.0;
+        for (int g = 0; g < groups; ++g) {
+            double s1 = 0;
+            for (int ci = g * gsz; ci < (g + 1) * gsz; ++ci) {
+                const float wg = w[(size_t)m * Ci + ci] * gamma[ci];
+                p[widx(0, ci, m, Ci, Mp)] = wg;
+                s1 += (double)wg;
+                s2 += (double)w[(size_t)m * Ci + ci] * (double)beta[ci];
+            }
+            cg[(size_t)g * Mp + m] = (float)s1;
+        }
+        c2[m] = (float)s2;
+    }
+    out.w = o.upload(p);
+    out.bias = nullptr;
+    out.Co = Co; out.Ci = Ci; out.K = 1; out.Mp = Mp;
+    cg_out = o.upload(cg);
+    c2_out = o.upload(c2);
+    return out.w && cg_out && c2_out;
+}
+
 // ConvTranspose1d (reference models.py:233-236) as `stride` interleaved phase filters of K/stride taps:
 // packed[tap][ci][co*stride + phi] = w[ci][co][phi + stride*(KT-1-tap)]
 static bool pack_convT(Owner& o, const float* w, const float* b, int Ci, int Co, int K, int stride, ConvW& out) {
@@ -445,11 +473,13 @@ struct DOpt {
     float act_slope = 0.f; float* out_act = nullptr; const float* acc_in = nullptr; float out_div = 1.f;
     int ph_log2 = 0, ph_tpad = 0, ph_Tout = 0;      // polyphase ConvTranspose output (kernels.h)
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
+    const float2* gnf_part = nullptr; int gnf_groups = 0; float gnf_eps = 1e-5f; const float* gnf_cg = nullptr; const float* gnf_c2 = nullptr;   // GroupNorm fold
     int cfg = 0;
     int out_f32 = 0;      // split-bf16 path: the K4P-range output channels stay fp32 K4P (q / k for the attention kernel)
 };
 // Batch size the launchers judge their tile / split choices at while a UNet call of this thread is running: 0 = the nominal batch (the
 // default: results do not depend on the batch split), the actual batch in latency mode (lds_unet_set_latency_mode).
+static std::atomic<int> g_gn_fold{1};      // lds_debug_set_gn_fold: 0 = the transformer's GroupNorm as its own pass (A/B measurements, tests)
 static thread_local int tl_tile_batch = 0;
 // ... and the scratch of the latency mode's cluster split-K (kernels.h DmaConvArgs::ksplit): partial tiles + arrival counters
 constexpr long long kClusterPartFloats = 4ll << 20;      // 16 MB: 320 workgroups x 4 waves x 1024 floats = 1.3 M floats are ever in use
@@ -478,6 +508,7 @@ static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, 
     a.out2 = o.out2; a.vt_D = o.vt_D; a.lnpart_out = o.lnpart_out; a.gnpart_out = o.gnpart_out;
     a.voc = o.voc; a.dil = o.dil; a.xpad = o.xpad; a.opad = o.opad; a.act_slope = o.act_slope; a.out_act = o.out_act; a.acc_in = o.acc_in; a.out_div = o.out_div;
     a.ln_part = o.ln_part; a.ln_np = o.ln_np; a.ln_eps = o.ln_eps; a.ln_c1 = o.ln_c1; a.ln_c2 = o.ln_c2;
+    a.gnf_part = o.gnf_part; a.gnf_groups = o.gnf_groups; a.gnf_eps = o.gnf_eps; a.gnf_cg = o.gnf_cg; a.gnf_c2 = o.gnf_c2;
     a.ph_log2 = o.ph_log2; a.ph_tpad = o.ph_tpad; a.ph_Tout = o.ph_Tout; a.ph_Cout = o.ph_Tout ? (W.Co >> o.ph_log2) : 0;
     const int Tin = o.ups ? 2 * Tsrc : Tsrc;
     a.To = (Tin + 2 * o.pad - o.dil * (W.K - 1) - 1) / o.stride + 1;
@@ -654,6 +685,8 @@ struct TfmW {
     float *gn_g = nullptr, *gn_b = nullptr;
     float *qkv_c1[2] = {nullptr, nullptr}, *qkv_c2[2] = {nullptr, nullptr}, *ff1_c1 = nullptr, *ff1_c2 = nullptr;   // folded LayerNorm constants
     ConvW proj_in, qkv[2], o[2], ff1, ff2_out;      // ff2_out = ff.net.2 and proj_out composed (load_tfm)
+    // `norm` (GroupNorm, no activation) folded into proj_in (pack_gn_fold): one launch and one activation round trip fewer per block
+    ConvW proj_in_g; float *pi_cg = nullptr, *pi_c2 = nullptr; bool fold = false;
 };
 struct DownBlk { std::vector<ResnetW> res; std::vector<TfmW> att; bool has_down = false; ConvW down; int ch = 0; };
 struct UpBlk { std::vector<ResnetW> res; std::vector<TfmW> att; std::vector<int> skip_ch; bool has_up = false; ConvW up; int ch = 0; };
@@ -729,6 +762,8 @@ static bool load_tfm(lds_unet* u, Tensors& T, const std::string& p, int C, TfmW&
     const float* pob = T.get(p + "proj_out.bias", C);
     if (!t.gn_g || !t.gn_b || !piw || !pib || !pow_ || !pob) return false;
     if (!pack_conv(o, piw, pib, C, C, 1, t.proj_in)) return false;
+    t.fold = u->G <= 8 && C % u->G == 0 && (C / u->G) % 16 == 0;
+    if (t.fold && !pack_gn_fold(o, piw, pib, T.get(p + "norm.weight", C), T.get(p + "norm.bias", C), C, C, u->G, t.proj_in_g, t.pi_cg, t.pi_c2)) return false;
     const std::string b = p + "transformer_blocks.0.";
     const float *lg[3], *lb[3];
     for (int i = 0; i < 3; ++i) {
@@ -1106,10 +1141,17 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     // applies the LayerNorm in its epilogue (weights pre-multiplied by gamma, pack_ln_fold).
     const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     const int C = t.C;
-    HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
     DOpt op;
     op.lnpart_out = w.lnp;
-    LDS_TRY(dconv_any(bf3, t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
+    if (t.fold && bf3 == 0 && g_gn_fold.load(std::memory_order_relaxed)) {
+        // proj_in(GroupNorm(x)) in one launch: the statistics come from the partials x's producer wrote, the normalisation is a rescaling
+        // of the accumulators between groups and a per-row constant (kernels.h DmaConvArgs::gnf_part)
+        op.gnf_part = w.gp(x); op.gnf_groups = u->G; op.gnf_eps = 1e-6f; op.gnf_cg = t.pi_cg; op.gnf_c2 = t.pi_c2;
+        LDS_TRY(dconv_any(bf3, t.proj_in_g, x, C, nullptr, 0, T, op, w.ta, B, st));
+    } else {
+        HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
+        LDS_TRY(dconv_any(bf3, t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
+    }
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
@@ -1999,6 +2041,42 @@ extern "C" int lds_test_gn_chain_k4p(const float* x, const float* w1, const floa
 }
 
 // mid = w1 * x (1x1, emits LayerNorm partials); out = w2 * LayerNorm_C(mid) with the LayerNorm folded into conv2's epilogue
+// conv (1x1, GroupNorm partials from its epilogue) -> proj(GroupNorm(mid)) as ONE launch with the normalisation folded (DmaConvArgs::gnf_part)
+extern "C" int lds_test_gn_fold_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps, int groups,
+                                    const float* w2, const float* bias2, float* mid, float* out, int B, int C, int Cm, int Co, int T, int cfg, int tile_batch,
+                                    void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Owner own;
+    TmpDev tmp;
+    ConvW W1, W2;
+    float *cg = nullptr, *c2 = nullptr;
+    if (!pack_conv(own, w1, bias1, Cm, C, 1, W1) || !pack_gn_fold(own, w2, bias2, gamma, beta, Co, Cm, groups, W2, cg, c2)) return fail(LDS_ENOMEM, "upload failed");
+    const int nT = (T + 31) / 32;
+    float* kx = tmp.f((size_t)B * C * (T + 2));
+    float* km = tmp.f((size_t)B * Cm * (T + 2));
+    float* ko = tmp.f((size_t)B * Co * (T + 2));
+    float* gp = tmp.f((size_t)B * (Cm / 16) * nT * 2);
+    float* kpart = tmp.f((size_t)kClusterPartFloats);
+    unsigned* kcount = (unsigned*)tmp.f(kClusterCounters);
+    if (!kx || !km || !ko || !gp || !kpart || !kcount) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(hipMemsetAsync(kcount, 0, sizeof(unsigned) * kClusterCounters, st));
+    HIP_TRY(launch_to_k4p(x, kx, B, C, T, C, 0, st));
+    DOpt o1;
+    o1.gnpart_out = (float2*)gp;
+    LDS_TRY(run_dconv(W1, kx, C, nullptr, 0, T, o1, km, B, st));
+    {
+        TileBatchScope tbs(tile_batch, kpart, kcount);      // tile_batch > 0: the latency mode's choices (cluster split-K through the fold)
+        DOpt o2;
+        o2.cfg = cfg;
+        o2.gnf_part = (const float2*)gp; o2.gnf_groups = groups; o2.gnf_eps = eps; o2.gnf_cg = cg; o2.gnf_c2 = c2;
+        LDS_TRY(run_dconv(W2, km, Cm, nullptr, 0, T, o2, ko, B, st));
+    }
+    HIP_TRY(launch_from_k4p(km, mid, B, Cm, T, st));
+    HIP_TRY(launch_from_k4p(ko, out, B, Co, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
 extern "C" int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
                                      float* mid, float* out, int B, int C, int Co, int T, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -2163,6 +2241,10 @@ extern "C" int lds_test_gn_apply_split(const float* x1, const float* x2, int C1,
     return LDS_OK;
 }
 
+extern "C" int lds_debug_set_gn_fold(int on) {
+    g_gn_fold.store(on ? 1 : 0);
+    return LDS_OK;
+}
 extern "C" int lds_debug_set_split_rule(int rule) {
     conv_bf3_set_debug_rule(rule);
     return LDS_OK;

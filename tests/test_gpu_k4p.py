@@ -224,6 +224,37 @@ def test_groupnorm_chain_k4p(C, Co, T, B, cfg, silu):
     assert relmax(out.cpu().numpy(), ref) < 2e-5, relmax(out.cpu().numpy(), ref)
 
 
+# (Cm = the normalised tensor's channels: group sizes 32 / 48 / 64; T, B pick the tile: 64 x 64 / 128 x 64 at full grids, the 32 x 64 split-K
+#  tile at small ones; tile_batch > 0 = the latency mode's choice with a workgroup cluster per tile)
+@pytest.mark.parametrize("Cm,T,B,tile_batch", [(256, 512, 16, 0), (256, 512, 2, 0), (384, 256, 16, 0), (384, 256, 2, 0), (384, 100, 1, 0), (512, 128, 16, 0),
+                                               (512, 64, 3, 0), (512, 37, 1, 0), (256, 512, 1, 1), (384, 256, 1, 1), (512, 128, 2, 2), (512, 64, 1, 1),
+                                               (128, 70, 2, 0)])
+def test_groupnorm_fold_k4p(Cm, T, B, tile_batch, record_margin):
+    """the transformer blocks' `norm` (GroupNorm, affine, no activation) folded into proj_in (reference transformer_1d.py:256-266): the
+    1x1 convolution reads the un-normalised tensor, rescales its accumulators between groups and adds a per-row constant; statistics
+    from the producer's epilogue partials.  The normalised tensor's mean is well away from zero (the fold subtracts mean * sum(W))."""
+    from lds import native
+    from oracle import unet1d
+    C, Co = 64, Cm
+    x = U(f"gnf{Cm}.{T}.x", (B, C, T), -2, 2)
+    w1 = (U(f"gnf{Cm}.{T}.w1", (Cm, C)) / np.float32(np.sqrt(C))).astype(np.float32)
+    b1 = U(f"gnf{Cm}.{T}.b1", (Cm,), 0.5, 1.5)
+    g, be = U(f"gnf{Cm}.{T}.g", (Cm,), 0.5, 1.5), U(f"gnf{Cm}.{T}.b", (Cm,), -0.5, 0.5)
+    w2 = (U(f"gnf{Cm}.{T}.w2", (Co, Cm)) / np.float32(np.sqrt(Cm))).astype(np.float32)
+    b2 = U(f"gnf{Cm}.{T}.b2", (Co,), -0.5, 0.5)
+    mid = torch.full((B, Cm, T), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.full((B, Co, T), float("nan"), dtype=torch.float32, device="cuda")
+    dx = dev(x)
+    P = lambda a: ct.c_void_p(a.ctypes.data)
+    native.check(native.lib().lds_test_gn_fold_k4p(ct.c_void_p(dx.data_ptr()), P(w1), P(b1), P(g), P(be), ct.c_float(1e-6), 8, P(w2), P(b2),
+                                                   ct.c_void_p(mid.data_ptr()), ct.c_void_p(out.data_ptr()), B, C, Cm, Co, T, 0, tile_batch, stream()))
+    torch.cuda.synchronize()
+    rmid = unet1d.conv1d(x, w1[:, :, None], b1)
+    ref = unet1d.conv1d(unet1d.group_norm(rmid, g, be, 8, 1e-6), w2[:, :, None], b2)
+    assert relmax(mid.cpu().numpy(), rmid) < 2e-5
+    record_margin(relmax(out.cpu().numpy(), ref), 2e-5)
+
+
 @pytest.mark.parametrize("C,Co,T,B", [(256, 768, 64, 2), (384, 384, 100, 1), (512, 1536, 37, 2)])
 def test_layernorm_chain_k4p(C, Co, T, B):
     from lds import native

@@ -12,6 +12,8 @@ from lds import init_weights  # noqa: E402
 
 B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 512
 m = Unit2Mel(1280, 323, 80).to("cuda").eval()
+m.decoder.denoise_fn.set_gemm_mode(os.environ.get("MODE", "f32"))          # MODE=split_f16 LAT=1: the GEMM / latency modes
+m.decoder.denoise_fn.set_latency_mode(os.environ.get("LAT", "0") == "1")
 units = torch.from_numpy(init_weights.uniform("bench.units", (B, T, 1280), 1, -1.7, 1.7)).cuda()
 spk = torch.ones(B, 1, dtype=torch.int64, device="cuda")
 
