@@ -15,6 +15,7 @@
 //     the value rows in its VT layout, eps in the caller's frame-major layout).
 // Reference operator set: LoRACompatibleConv / Linear of the UNet (reference diffusion/unet1d/resnet.py:591-641, attention.py:130-301).
 #include "k4p.h"
+#include "gn_chan.h"
 #include "k8b3.h"
 #include "kernels.h"
 
@@ -86,7 +87,10 @@ struct Bf3Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "stages exceed the LDS");
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT = FMT_BF16X3>
+// GNF: the GroupNorm fold of DmaConvArgs::gnf_part (separate instantiations).  The split planes cannot be scaled on their way to the
+// MFMA (a 16-bit term times an fp32 rstd is no 16-bit term), so here the fp32 accumulators change their unit at group boundaries:
+// sum_g rstd_g S_g = ((S_0 r_0/r_1 + S_1) r_1/r_2 + ...) r_last, one multiplication of the accumulators per boundary of a wave's K range.
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT = FMT_BF16X3, bool GNF = false>
 struct Bf3Kernel {
     using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>;
     static constexpr int NPL = Cfg::NPL;
@@ -99,6 +103,11 @@ struct Bf3Kernel {
     float* smem;
     int lane, wave, c, h, wm, wn, ks, b, m0, t0;
     int ksp, kc0, ctile;      // cluster split-K (latency mode; conv_dma.hip cluster_join): share index, first K-step, tile index
+    // GroupNorm fold: (threads < BM) the terms of their row's constant, this wave's two groups' partial statistics (both in flight across
+    // the first DMAs), the group of this wave's share of the current K-step and the share's channel offset inside it
+    float gcg[GNF ? 8 : 1], gkc;
+    GnPart gp0, gp1;
+    int ggi, gpos;
     int woff[NWI];            // per-lane byte offsets of this wave's weight chunks (loop invariant)
     int xoff[NXI];            // per-lane byte offsets of this wave's activation chunks inside a source slab
     __amdgpu_buffer_rsrc_t rw, rx1, rx2;
@@ -230,6 +239,68 @@ struct Bf3Kernel {
         mfma_pair<SLOT, 0, 0>();
     }
 
+    // ---- GroupNorm fold (DmaConvArgs::gnf_part; conv_dma.hip has the fp32 twin) ----
+    // LDS behind the ring: [0, BM) the per-row constants, then 8 x rstd_g, 8 x 1 / rstd_g, 8 x rstd_g * mean_g of this batch element
+    __device__ __forceinline__ float* gnf_tail() const { return smem + NST * STAGE + BM; }
+    __device__ __forceinline__ void gnf_scale(float f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+    }
+    __device__ __forceinline__ void gnf_request() {      // kernel start, before the first DMA
+        const int G_ = p.gnf_groups, gsz = p.Ci / G_;
+        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0);
+        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0);
+        if ((int)threadIdx.x < BM) {
+            const int m = m0 + (int)threadIdx.x;
+            gkc = p.gnf_c2[m];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) gcg[g] = (g < G_) ? p.gnf_cg[g * p.Mp + m] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void gnf_prepare() {      // before the first barrier: wave w publishes groups w and w + 4
+        const int G_ = p.gnf_groups, gsz = p.Ci / G_;
+        float* tail = gnf_tail();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int g = wave + 4 * e;
+            float rs = 1.f, sd = 1.f, rm = 0.f;
+            if (g < G_) {
+                float mu, var;
+                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var);
+                sd = sqrtf(var + p.gnf_eps); rs = 1.0f / sd; rm = rs * mu;
+            }
+            if (lane == 0) { tail[g] = rs; tail[8 + g] = sd; tail[16 + g] = rm; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int span = SPLIT ? BK / 2 : BK;
+        const int start = kc0 * BK + ks * span;      // first channel of this wave's share of its first K-step
+        ggi = start / gsz; gpos = start - ggi * gsz;
+    }
+    __device__ __forceinline__ void gnf_rows() {         // after the first barrier: kc[m] = gnf_c2[m] - sum_g rstd_g mean_g gnf_cg[g][m]
+        if ((int)threadIdx.x < BM) {
+            const float* tail = gnf_tail();
+            float kc = gkc;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) kc = fmaf(-tail[16 + g], gcg[g], kc);
+            smem[NST * STAGE + threadIdx.x] = kc;
+        }
+    }
+    __device__ __forceinline__ void gnf_advance() {      // after a K-step that is not the last
+        const int gsz = p.Ci / p.gnf_groups;
+        gpos += BK;
+        int g1 = ggi;
+        while (gpos >= gsz) { gpos -= gsz; ++g1; }
+        if (g1 != ggi) {
+            const float* tail = gnf_tail();
+            gnf_scale(tail[ggi] * tail[8 + g1]);
+            ggi = g1;
+        }
+    }
+
     template <int Y>
     __device__ __forceinline__ void wait_younger(int y) {      // s_waitcnt vmcnt(y * PER_TILE) for a wave-uniform y in [0, Y]
         if constexpr (Y == 0) {
@@ -319,12 +390,15 @@ struct Bf3Kernel {
 
     __device__ __forceinline__ void mainloop() {
         const int nk = p.Ci / BK / (p.ksplit > 1 ? p.ksplit : 1);      // this workgroup's K-steps: kc0 .. kc0 + nk - 1
+        if constexpr (GNF) gnf_request();
         if constexpr (EARLY) early_loads();
         for (int t = 0; t < NST && t < nk; ++t) issue_tile(kc0 + t, smem + t * STAGE);
         if (p.ln_part) ln_columns();
+        if constexpr (GNF) gnf_prepare();
         wait_younger<NST - 1>((nk - 1 < NST - 1) ? nk - 1 : NST - 1);      // tile 0 landed (this wave's share)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (GNF) gnf_rows();
         load_ops<0>(smem, 0, 0);
         int sc = 0;
         if constexpr (G % 2 == 0) {
@@ -332,18 +406,25 @@ struct Bf3Kernel {
                 const int sn = (sc + 1 == NST) ? 0 : sc + 1;
                 kstep<0, 0>(smem + sc * STAGE, smem + sn * STAGE, kc, nk);
                 sc = sn;
+                if constexpr (GNF) { if (kc + 1 < nk) gnf_advance(); }
             }
         } else {
             for (int kc = 0; kc < nk; kc += 2) {
                 int sn = (sc + 1 == NST) ? 0 : sc + 1;
                 kstep<0, 0>(smem + sc * STAGE, smem + sn * STAGE, kc, nk);
                 sc = sn;
+                if constexpr (GNF) { if (kc + 1 < nk) gnf_advance(); }
                 if (kc + 1 < nk) {
                     sn = (sc + 1 == NST) ? 0 : sc + 1;
                     kstep<0, 1>(smem + sc * STAGE, smem + sn * STAGE, kc + 1, nk);
                     sc = sn;
+                    if constexpr (GNF) { if (kc + 2 < nk) gnf_advance(); }
                 }
             }
+        }
+        if constexpr (GNF) {
+            gnf_scale(gnf_tail()[ggi]);      // the last group's rstd, before partial sums of different waves / workgroups meet
+            __syncthreads();                 // (the row constants are read in finalize: a one-K-step launch has met no barrier since)
         }
     }
 
@@ -377,6 +458,16 @@ struct Bf3Kernel {
                         const float v = acc[i][j][r];
                         acc[i][j][r] = ln ? lrs[j] * (v - lmu[j] * k1[i][r]) + k2[i][r] : v + k2[i][r];
                     }
+        }
+        if constexpr (GNF) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float kc = smem[NST * STAGE + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] += kc;
+                }
         }
         if (geglu) {      // rows of tile 0 are the values, rows of tile 1 the gates (pack_geglu)
 #pragma unroll
@@ -615,10 +706,10 @@ struct Bf3Kernel {
     }
 };
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT, bool GNF = false>
 __global__ void __launch_bounds__(256, (Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>::OCC)) conv_bf3_kernel(const DmaConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    Bf3Kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT> k(p, smem);
+    Bf3Kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT, GNF> k(p, smem);
     k.setup();
     k.mainloop();
     k.epilogue();
@@ -658,26 +749,29 @@ __global__ void __launch_bounds__(256, (Bf3PairCfg<BM, BN, BK3, BK1, NST, FMT>::
 static thread_local char g_bcfg[112] = "";
 const char* conv_bf3_last_config() { return g_bcfg; }
 
-template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT>
+template <int BM, int BN, int KT, int STRIDE, bool UPS, int BK, int NST, int NPROD, int FMT, bool GNF = false>
 static hipError_t launch_bf3_cfg(const DmaConvArgs& a, hipStream_t s) {
     using Cfg = Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST, FMT>;
+    if (GNF != (a.gnf_part != nullptr)) return hipErrorInvalidValue;
+    const size_t lds_bytes = Cfg::LDS_BYTES + (GNF ? (BM + 32) * sizeof(float) : 0);      // the fold's row constants and group statistics sit behind the ring
     const int nN = (a.To + BN - 1) / BN;
     const int S = a.ksplit > 1 ? a.ksplit : 1;
     if (S > 1 && (Cfg::TM * Cfg::TN > 2 || (a.Ci / BK) % S)) return hipErrorInvalidValue;
     dim3 grid((a.Mp / BM) * nN, a.B * S);
-    auto kern = conv_bf3_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT>;
-    if (Cfg::LDS_BYTES > 48 * 1024) {
+    auto kern = conv_bf3_kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT, GNF>;
+    if (lds_bytes > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kern), attr_done);
         if (e != hipSuccess) return e;
     }
-    if (S > 1) snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d KS%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST,
-                        FMT == FMT_F16X2 ? "H" : "P", NPROD, S, grid.x, grid.y, Cfg::LDS_BYTES);
-    else snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, FMT == FMT_F16X2 ? "H" : "P",
-             NPROD, grid.x, grid.y, Cfg::LDS_BYTES);
+    const char* gtag = GNF ? " GNF" : "";
+    if (S > 1) snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d KS%d%s grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST,
+                        FMT == FMT_F16X2 ? "H" : "P", NPROD, S, gtag, grid.x, grid.y, lds_bytes);
+    else snprintf(g_bcfg, sizeof(g_bcfg), "BM%d BN%d KT%d S%d U%d BK%d NST%d %s%d%s grid %ux%u lds %zu", BM, BN, KT, STRIDE, (int)UPS, BK, NST, FMT == FMT_F16X2 ? "H" : "P",
+             NPROD, gtag, grid.x, grid.y, lds_bytes);
     hipEvent_t e0, e1;
-    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, e0, e1, 0, a);
-    else hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -818,6 +912,23 @@ static hipError_t split_dispatch(const DmaConvArgs& a_, int cfg, int nprod, hipS
     if ((bk == 64 && !k64) || (bk == 32 && !k32)) return hipErrorInvalidValue;
     if (a.epi == EPI_GEGLU && bm != 128) return hipErrorInvalidValue;
     if (a.Mp % bm) return hipErrorInvalidValue;
+    if (a.gnf_part) {
+        // GroupNorm fold: a 1x1 convolution over one source; every wave's share of a K-step inside one group (conv_dma.hip launch_conv_dma)
+        if (a.KT != 1 || a.stride != 1 || a.ups || a.C2 != 0 || a.x2 || a.ln_part || a.epi != EPI_NONE || a.bias || !a.gnf_cg || !a.gnf_c2 || a.gnf_groups < 1 ||
+            a.gnf_groups > 8 || a.Ci % a.gnf_groups || (a.Ci / a.gnf_groups) % 16 || nprod != (FMT == FMT_F16X2 ? 3 : 6))
+            return hipErrorInvalidValue;
+        const int gsz = a.Ci / a.gnf_groups;
+        if (bm * bn > 128 * 64) bn = 64;
+        while (gsz % (bm == 32 ? bk / 2 : bk)) bk /= 2;
+        if (bm == 32) nst = 2;
+        else if (bm == 64) nst = 3;
+        else nst = (bk == 32) ? 2 : 3;
+        if (cfg == 0) a.ksplit = bf3_cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
+#define GBCASE(BM, BN, BK, NS) if (bm == BM && bn == BN && bk == BK && nst == NS) return launch_bf3_cfg<BM, BN, 1, 1, false, BK, NS, (FMT == FMT_F16X2 ? 3 : 6), FMT, true>(a, s)
+        GBCASE(32, 64, 32, 2); GBCASE(32, 64, 64, 2); GBCASE(64, 64, 32, 3); GBCASE(64, 64, 16, 3); GBCASE(128, 64, 32, 2); GBCASE(128, 64, 16, 3);
+#undef GBCASE
+        return hipErrorInvalidValue;
+    }
     if (cfg == 0) a.ksplit = bf3_cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const int tk = bm * 1000 + bn;

@@ -980,7 +980,7 @@ static bool unet_pack_split(lds_unet* u, int fmt) {
         if (r.has_sc) ok = ok && make_split_twin_pair(o, r.conv2, r.sc, fmt);
         else T1(r.conv2);
     };
-    auto tfm = [&](TfmW& t) { T1(t.proj_in); T1(t.qkv[0]); T1(t.qkv[1]); T1(t.o[0]); T1(t.o[1]); T1(t.ff1); T1(t.ff2_out); };
+    auto tfm = [&](TfmW& t) { T1(t.proj_in); if (t.fold) T1(t.proj_in_g); T1(t.qkv[0]); T1(t.qkv[1]); T1(t.o[0]); T1(t.o[1]); T1(t.ff1); T1(t.ff2_out); };
     T1(u->conv_in); T1(u->conv_in_x); T1(u->conv_in_c); T1(u->conv_out);
     for (auto& d : u->down) {
         for (auto& r : d.res) res(r);
@@ -1143,7 +1143,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     const int C = t.C;
     DOpt op;
     op.lnpart_out = w.lnp;
-    if (t.fold && bf3 == 0 && g_gn_fold.load(std::memory_order_relaxed)) {
+    if (t.fold && g_gn_fold.load(std::memory_order_relaxed)) {
         // proj_in(GroupNorm(x)) in one launch: the statistics come from the partials x's producer wrote, the normalisation is a rescaling
         // of the accumulators between groups and a per-row constant (kernels.h DmaConvArgs::gnf_part)
         op.gnf_part = w.gp(x); op.gnf_groups = u->G; op.gnf_eps = 1e-6f; op.gnf_cg = t.pi_cg; op.gnf_c2 = t.pi_c2;
