@@ -76,6 +76,9 @@ int lds_test_conv_transpose(const float* x, const float* w /*host [Ci,Co,K]*/, c
 int lds_test_dconv_bf3(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, void* stream);
 int lds_bench_dconv_bf3(const lds_dconv_test* a, float* out, int B, int iters, int nprod, float* ms_out, char* cfg_out, size_t cfg_cap,
                         void* stream);
+/* lds_bench_dconv with consecutive launches rotating through the tile configurations cfgs[0 .. n): the cost of running code the previous
+ * launch did not run (tools/bench_icache.py) */
+int lds_bench_dconv_alt(const lds_dconv_test* a, float* out, int B, int iters, const int* cfgs, int n, float* ms_out, void* stream);
 /* the same through either split-plane format: fmt 0 = three bf16 planes, 1 = two fp16 planes (csrc/k8b3.h); nprod 0 = the format's default */
 int lds_test_dconv_split(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, int fmt, void* stream);
 int lds_bench_dconv_split(const lds_dconv_test* a, float* out, int B, int iters, int nprod, int fmt, float* ms_out, char* cfg_out, size_t cfg_cap,

@@ -1836,7 +1836,8 @@ struct TmpDev {
 };
 
 // bf3 = 1: the same operator through the split-bf16 kernel (K8B3 tensors, conv_bf3.hip) with `nprod` bf16 products per fp32 product
-static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream, int bf3 = 0, int nprod = 0, int fmt = 0) {
+static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, int B, int iters, float* ms_out, void* stream, int bf3 = 0, int nprod = 0, int fmt = 0,
+                           const int* alt_cfgs = nullptr, int n_alt = 0) {
     hipStream_t st = (hipStream_t)stream;
     Owner own;
     TmpDev tmp;
@@ -1887,7 +1888,10 @@ static int dconv_test_impl(const lds_dconv_test* a, float* out, float* lnpart, i
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
-        for (int i = 0; i < iters && r == LDS_OK; ++i) r = run();
+        for (int i = 0; i < iters && r == LDS_OK; ++i) {
+            if (n_alt > 0) o.cfg = alt_cfgs[i % n_alt];      // lds_bench_dconv_alt: consecutive launches rotate through kernel instantiations
+            r = run();
+        }
         HIP_TRY(hipEventRecord(e1, st));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1928,6 +1932,12 @@ extern "C" int lds_bench_dconv(const lds_dconv_test* a, float* out, int B, int i
     int r = dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream);
     if (cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", conv_dma_last_config());
     return r;
+}
+// the same launch `iters` times, rotating through the tile configurations cfgs[0 .. n) (instantiations of the same operator): what does a
+// launch cost when the previous launch ran other code?  (tools/bench_icache.py)
+extern "C" int lds_bench_dconv_alt(const lds_dconv_test* a, float* out, int B, int iters, const int* cfgs, int n, float* ms_out, void* stream) {
+    if (!a || !out || !cfgs || n < 1 || !ms_out) return fail(LDS_EINVAL, "bad argument");
+    return dconv_test_impl(a, out, nullptr, B, iters, ms_out, stream, 0, 0, 0, cfgs, n);
 }
 extern "C" int lds_test_dconv_split(const lds_dconv_test* a, float* out, float* lnpart, int B, int nprod, int fmt, void* stream) {
     if (!a || !out || (fmt != FMT_BF16X3 && fmt != FMT_F16X2)) return fail(LDS_EINVAL, "bad argument");
