@@ -114,16 +114,17 @@ def _newest_profile_json(suffix):
 
 def _pmc_key(kernel_name):
     import re
-    m = re.match(r"(\w+)<BM(\d+) BN(\d+) KT(\d+) S(\d+) U(\d+) BK(\d+)(?: NST(\d+))?>", kernel_name)
+    m = re.match(r"(\w+)<BM(\d+) BN(\d+) KT(\d+) S(\d+) U(\d+) BK(\d+)(?: NST(\d+))?(?: KS\d+)?( GNF)?>", kernel_name)
     if not m:
         return None
-    fam, bm, bn, kt, st, up, bk, nst = m.groups()
-    # rocprofv3 prints every template argument: <BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC> (the UNet's kernels have DIL 1, VOC false)
-    return f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}, 1, false>" if nst else None
+    fam, bm, bn, kt, st, up, bk, nst, gnf = m.groups()
+    # rocprofv3 prints every template argument: <BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC, GNF> (the UNet's kernels have DIL 1, VOC false;
+    # GNF = the GroupNorm-fold instantiations)
+    return f"{fam}<{bm}, {bn}, {kt}, {st}, {'true' if up == '1' else 'false'}, {bk}, {nst}, 1, false, {'true' if gnf else 'false'}>" if nst else None
 
 
 # source files whose change invalidates a counter summary of a kernel family
-_FAMILY_SOURCES = {"conv_dma": ["conv_dma.hip", "k4p.h"], "conv_bf3": ["conv_bf3.hip", "k8b3.h"],
+_FAMILY_SOURCES = {"conv_dma": ["conv_dma.hip", "k4p.h", "gn_chan.h"], "conv_bf3": ["conv_bf3.hip", "k8b3.h"],
                    "attention": ["attention_k4p.hip", "k4p.h"], "gn_stream": ["k4p_ops.hip", "k4p.h"]}
 
 
