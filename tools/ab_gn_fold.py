@@ -1,7 +1,8 @@
-"""A/B on one box, one process: the sampler step with the transformer blocks' GroupNorm folded into proj_in (default) and as its own pass
-(lds_debug_set_gn_fold(0)), in the exact-fp32 and the split-fp16 GEMM modes, default and latency mode.
+"""A/B on one box, one process: the sampler step with a library switch on (default) and off, in the exact-fp32 and the split-fp16 GEMM
+modes, default and latency mode.  Switches: gn_fold (the transformer blocks' GroupNorm folded into proj_in vs its own pass),
+cluster_default (cluster split-K on the T/8 level's split tiles in the default mode vs none).
 
-    python tools/ab_gn_fold.py
+    python tools/ab_gn_fold.py [gn_fold | cluster_default]
 """
 import os
 import sys
@@ -14,6 +15,8 @@ import torch  # noqa: E402
 from diffusion.unit2mel import Unit2Mel  # noqa: E402
 from lds import init_weights, native  # noqa: E402
 
+SWITCH = sys.argv[1] if len(sys.argv) > 1 else "gn_fold"
+setter = {"gn_fold": native.lib().lds_debug_set_gn_fold, "cluster_default": native.lib().lds_debug_set_cluster_default}[SWITCH]
 T = 512
 m = Unit2Mel(1280, 323, 80).to("cuda").eval()
 unet = m.decoder.denoise_fn
@@ -40,7 +43,7 @@ for mode in ("f32", "split_f16"):
         unet.set_latency_mode(lat)
         res = {}
         for fold in (1, 0, 1, 0):
-            native.lib().lds_debug_set_gn_fold(fold)
+            setter(fold)
             res.setdefault(fold, []).append(timeit(B))
-        native.lib().lds_debug_set_gn_fold(1)
-        print(f"{mode:10s} B={B:2d} latency_mode={int(lat)}: fold on {min(res[1]):7.2f} ms, off {min(res[0]):7.2f} ms  ({res})", flush=True)
+        setter(1)
+        print(f"{SWITCH} {mode:10s} B={B:2d} latency_mode={int(lat)}: on {min(res[1]):7.2f} ms, off {min(res[0]):7.2f} ms  ({res})", flush=True)
