@@ -89,8 +89,6 @@ int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, in
 /* tuning only (tools/tune_split_rules.py): bit mask of alternative tile rules of the split-GEMM launcher, 0 = the shipped rules */
 /* 0: the transformer blocks' GroupNorm runs as its own pass instead of folded into proj_in (A/B measurements and tests); default 1 */
 int lds_debug_set_gn_fold(int on);
-/* 0: no cluster split-K in the default (batch-invariant) mode (A/B measurements); default 1 */
-int lds_debug_set_cluster_default(int on);
 int lds_debug_set_split_rule(int rule);
 /* plain [B,C,T] -> K8B3 -> plain: must return the input bit for bit (the three-term split is lossless) */
 int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream);

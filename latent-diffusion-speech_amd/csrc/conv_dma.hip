@@ -932,23 +932,9 @@ static void dma_pick(const DmaConvArgs& a, int cfg, int& bm, int& bn, int& bk, i
 
 // Latency mode: how many workgroups share one output tile's K range (1 = no cluster split).  Doubled while the grid stays within
 // one workgroup per CU (a CU with two takes twice as long), the K-steps divide evenly and every share keeps >= min_steps of them.
-static std::atomic<int> g_cluster_default{1};
-void conv_dma_set_cluster_default(int on) { g_cluster_default.store(on ? 1 : 0); }
 static int cluster_split(const DmaConvArgs& a, int bm, int bn, int nk, int nk2, int min_steps) {
-    if (!a.kpart || !a.kcount || a.voc || bm * bn > 128 * 64) return 1;
+    if (a.tile_batch <= 0 || !a.kpart || !a.kcount || a.voc || bm * bn > 128 * 64) return 1;
     const int blk = bm * bn > 64 * 64 ? 2 : 1;      // 32 x 32 blocks per wave
-    if (a.tile_batch <= 0) {
-        // Default mode: judged per utterance at the nominal batch of 16, never at the actual one (the split fixes the order of the
-        // reduction: an utterance's result must not depend on its batch).  A grid of at most one split tile per CU (the T/8 level)
-        // leaves every SIMD with a single wave, which reaches ~0.62 of the matrix rate and walks the whole K range alone; two
-        // workgroups per tile put two waves on every SIMD and halve the chain.  Shares keep >= 4 K-steps.
-        if (!g_cluster_default.load(std::memory_order_relaxed) || bm != 32) return 1;
-        const long long per_utt = (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn);
-        int S = 1;
-        while (S < 4 && per_utt * 16 * S * 2 <= 512 && nk % (S * 2) == 0 && nk / (S * 2) >= 4 && (nk2 == 0 || (nk2 % (S * 2) == 0))) S *= 2;
-        if (per_utt * a.B * 4 > a.kcount_cap || per_utt * a.B * 4 * S * blk * 1024 > a.kpart_cap) return -1;      // (the workspace planner sizes both by B)
-        return S;
-    }
     const long long tiles = (long long)(a.Mp / bm) * ((a.To + bn - 1) / bn) * a.B;
     if (tiles * 4 > a.kcount_cap) return 1;
     int S = 1;
@@ -1004,7 +990,6 @@ hipError_t launch_conv_dma_pair(const DmaConvArgs& a3_, const DmaConvArgs& a1_, 
     if (pv) {
         const int bm = pv >> 16, bn = (pv >> 8) & 255, bk1 = pv & 255;
         a3.ksplit = a1.ksplit = cluster_split(a1, bm, bn, a3.Ci / 32, a1.Ci / bk1, 1);
-        if (a1.ksplit < 0) return hipErrorInvalidValue;
     }
     switch (pv) {
         case (32 << 16) | (64 << 8) | 64: return launch_pair_cfg<32, 64, 32, 64, 2>(a3, a1, s);
@@ -1060,14 +1045,12 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_, int cfg, hipStream_t s) {
         while (gsz % (bm == 32 ? bk / 2 : bk)) bk /= 2;      // (a split tile's half K-step of 16 channels divides every group size)
         if (bm != 32 && bk == 16) nst = 3;
         if (cfg == 0) a.ksplit = cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
-        if (a.ksplit < 0) return hipErrorInvalidValue;
 #define GCASE(BM, BN, BK, NS) if (bm == BM && bn == BN && bk == BK && nst == NS) return launch_dma_cfg<BM, BN, 1, 1, false, BK, NS, 1, false, true>(a, s)
         GCASE(32, 64, 32, 2); GCASE(32, 64, 64, 2); GCASE(64, 64, 32, 2); GCASE(64, 64, 16, 3); GCASE(128, 64, 32, 2); GCASE(128, 64, 16, 3);
 #undef GCASE
         return hipErrorInvalidValue;
     }
     if (cfg == 0) a.ksplit = cluster_split(a, bm, bn, a.Ci / bk, 0, 2);
-    if (a.ksplit < 0) return hipErrorInvalidValue;
     const int key = a.KT * 100 + a.stride * 10 + (a.ups ? 1 : 0);
     const int tk = bm * 1000 + bn;
     if (key == 110) {

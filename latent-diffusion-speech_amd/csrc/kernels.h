@@ -124,7 +124,6 @@ hipError_t launch_conv_dma(const DmaConvArgs& a, int cfg, hipStream_t s);
 hipError_t launch_conv_dma_pair(const DmaConvArgs& a3, const DmaConvArgs& a1, hipStream_t s);
 bool conv_dma_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1);
 const char* conv_dma_last_config();
-void conv_dma_set_cluster_default(int on);      // A/B switch (lds_debug_set_cluster_default): cluster split-K in the default mode
 
 // ---------------------------------------------------------------------------------------------
 // conv_bf3: the same operator on the bf16 matrix pipe with fp32-equivalent split operands (conv_bf3.hip, k8b3.h).  Same argument

@@ -482,29 +482,22 @@ struct DOpt {
 static std::atomic<int> g_gn_fold{1};      // lds_debug_set_gn_fold: 0 = the transformer's GroupNorm as its own pass (A/B measurements, tests)
 static thread_local int tl_tile_batch = 0;
 // ... and the scratch of the latency mode's cluster split-K (kernels.h DmaConvArgs::ksplit): partial tiles + arrival counters
-// Scratch sizes for a batch of B: the latency mode keeps a launch within 256 workgroups (x 4 waves x 2 blocks x 1024 floats); the default
-// mode's cluster split (conv_dma.hip cluster_split, judged per utterance at the nominal batch) within 32 workgroup shares per utterance.
-static long long cluster_part_floats(int B) { return std::max<long long>(4ll << 20, (long long)B * 32 * 4 * 2 * 1024); }
-static int cluster_counters(int B) { return std::max(4096, B * 32 * 4); }
-constexpr long long kClusterPartFloats = 4ll << 20;      // (test entry points: B <= 16)
+constexpr long long kClusterPartFloats = 4ll << 20;      // 16 MB: 320 workgroups x 4 waves x 1024 floats = 1.3 M floats are ever in use
 constexpr int kClusterCounters = 4096;
 static thread_local float* tl_kpart = nullptr;
 static thread_local unsigned* tl_kcount = nullptr;
-static thread_local long long tl_kpart_cap = 0;
-static thread_local int tl_kcount_cap = 0;
 struct TileBatchScope {
-    int prev; float* pp; unsigned* pc; long long ppc; int pcc;
-    explicit TileBatchScope(int tb, float* kpart = nullptr, unsigned* kcount = nullptr, long long part_cap = kClusterPartFloats, int count_cap = kClusterCounters)
-        : prev(tl_tile_batch), pp(tl_kpart), pc(tl_kcount), ppc(tl_kpart_cap), pcc(tl_kcount_cap) {
-        tl_tile_batch = tb; tl_kpart = kpart; tl_kcount = kcount; tl_kpart_cap = part_cap; tl_kcount_cap = count_cap;
+    int prev; float* pp; unsigned* pc;
+    explicit TileBatchScope(int tb, float* kpart = nullptr, unsigned* kcount = nullptr) : prev(tl_tile_batch), pp(tl_kpart), pc(tl_kcount) {
+        tl_tile_batch = tb; tl_kpart = tb ? kpart : nullptr; tl_kcount = tb ? kcount : nullptr;
     }
-    ~TileBatchScope() { tl_tile_batch = prev; tl_kpart = pp; tl_kcount = pc; tl_kpart_cap = ppc; tl_kcount_cap = pcc; }
+    ~TileBatchScope() { tl_tile_batch = prev; tl_kpart = pp; tl_kcount = pc; }
 };
 
 static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, DmaConvArgs& a) {
     memset(&a, 0, sizeof(a));
     a.tile_batch = tl_tile_batch;
-    a.kpart = tl_kpart; a.kcount = tl_kcount; a.kpart_cap = tl_kpart_cap; a.kcount_cap = tl_kcount_cap;
+    a.kpart = tl_kpart; a.kcount = tl_kcount; a.kpart_cap = kClusterPartFloats; a.kcount_cap = kClusterCounters;
     if (C1 + C2 != W.Ci) return fail(LDS_EINVAL, "dconv: input channels %d+%d != %d", C1, C2, W.Ci);
     a.x1 = x1; a.x2 = x2 ? x2 : x1; a.C1 = C1; a.C2 = C2; a.Tsrc = Tsrc;
     a.w = W.w; a.bias = W.bias; a.Mp = W.Mp; a.Co = W.Co; a.Ci = W.Ci; a.KT = W.K;
@@ -1102,8 +1095,8 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.gno = A.f(B * maxgn);
     w.qk = A.f(B * maxatt * 2); w.v = A.f(B * (maxatt + 2048)); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
     w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2);
-    w.kpart = A.f(cluster_part_floats(B));
-    w.kcount = (unsigned*)A.f(cluster_counters(B));
+    w.kpart = u->latency_mode ? A.f(kClusterPartFloats) : nullptr;
+    w.kcount = u->latency_mode ? (unsigned*)A.f(kClusterCounters) : nullptr;
     A.f(16384);   // tail slack: ragged last tiles read (masked) entries past a tensor's end
 }
 
@@ -1199,8 +1192,8 @@ static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_b
     UnetWs w;
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
-    TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount, cluster_part_floats(B), cluster_counters(B));
-    HIP_TRY(launch_fill((float*)w.kcount, 0.f, cluster_counters(B), st));      // (bit pattern 0 = counter 0)
+    TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
+    if (u->latency_mode) HIP_TRY(launch_fill((float*)w.kcount, 0.f, kClusterCounters, st));      // (bit pattern 0 = counter 0)
     // conv_in is linear in its input channels: the condition's contribution (and the bias) is the same for every evaluation of the run.
     // It is computed here once; an evaluation convolves the 80 sample channels only and adds it as the residual (1008 -> 240 reduction
     // terms per output of conv_in, every NFE).
@@ -1220,9 +1213,9 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     UnetWs w;
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
-    TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount, cluster_part_floats(B), cluster_counters(B));
+    TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
     // the counters are left at zero by every launch that uses them; a forward starts from zeroed ones whatever the workspace held before
-    if (!cond_staged) HIP_TRY(launch_fill((float*)w.kcount, 0.f, cluster_counters(B), st));
+    if (u->latency_mode && !cond_staged) HIP_TRY(launch_fill((float*)w.kcount, 0.f, kClusterCounters, st));
     const int nb = u->cfg.n_blocks;
     const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     // time embedding (reference embeddings.py:24-64,157-201) and all resnets' time_emb_proj in one launch.
@@ -2258,10 +2251,6 @@ extern "C" int lds_test_gn_apply_split(const float* x1, const float* x2, int C1,
     return LDS_OK;
 }
 
-extern "C" int lds_debug_set_cluster_default(int on) {
-    conv_dma_set_cluster_default(on);
-    return LDS_OK;
-}
 extern "C" int lds_debug_set_gn_fold(int on) {
     g_gn_fold.store(on ? 1 : 0);
     return LDS_OK;

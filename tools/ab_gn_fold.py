@@ -1,8 +1,7 @@
 """A/B on one box, one process: the sampler step with a library switch on (default) and off, in the exact-fp32 and the split-fp16 GEMM
-modes, default and latency mode.  Switches: gn_fold (the transformer blocks' GroupNorm folded into proj_in vs its own pass),
-cluster_default (cluster split-K on the T/8 level's split tiles in the default mode vs none).
+modes, default and latency mode.  Switch: gn_fold (the transformer blocks' GroupNorm folded into proj_in vs its own pass).
 
-    python tools/ab_gn_fold.py [gn_fold | cluster_default]
+    python tools/ab_gn_fold.py [gn_fold]
 """
 import os
 import sys
@@ -16,7 +15,7 @@ from diffusion.unit2mel import Unit2Mel  # noqa: E402
 from lds import init_weights, native  # noqa: E402
 
 SWITCH = sys.argv[1] if len(sys.argv) > 1 else "gn_fold"
-setter = {"gn_fold": native.lib().lds_debug_set_gn_fold, "cluster_default": native.lib().lds_debug_set_cluster_default}[SWITCH]
+setter = {"gn_fold": native.lib().lds_debug_set_gn_fold}[SWITCH]
 T = 512
 m = Unit2Mel(1280, 323, 80).to("cuda").eval()
 unet = m.decoder.denoise_fn
