@@ -521,11 +521,43 @@ def extra_legs(args, dev, model, make_inputs):
     dt_lm = timeit(lm_only, 2)
     dt = timeit(full, 2)
     assert tuple(keep["tok"].shape) == (Bq, T) and bool(torch.isfinite(keep["wav"]).all())
+    unet.set_latency_mode(True)      # 8 utterances are half the nominal batch: the tile choices of the latency mode pay here too
+    try:
+        dt_lat = timeit(full, 2)
+    finally:
+        unet.set_latency_mode(False)
     extra["configs5_full_tts_per_gpu"] = {
         "workload": f"configs[5] per-GPU share: {Bq} utterances, {Lp} phones -> RoFormer top-k sampling of {T} semantic tokens -> {args.nfe}-step "
                     f"{args.method} -> HiFi-VAEGAN ({T * 512} samples/utt)",
         "ms_per_step": 1e3 * dt, "x_realtime": Bq * T * FRAME_SEC / dt, "rtf": dt / (Bq * T * FRAME_SEC),
         "lm_ms": 1e3 * dt_lm, "lm_tokens_per_sec": Bq * T / dt_lm, "lm_us_per_decode_step": 1e6 * dt_lm / T,
+        "latency_mode_ms_per_step": 1e3 * dt_lat, "latency_mode_x_realtime": Bq * T * FRAME_SEC / dt_lat,
+    }
+    # ---- configs[4] in small: a RAGGED batch, 16 utterances of 16 different lengths (272 .. 512 frames), tokens -> units -> mel -> wav.  Equal
+    #      lengths batch; different lengths run as buckets of one (infer_tts.synthesize_ragged), sequentially or overlapped on HIP streams ----
+    from diffusion.vocoder import Vocoder
+    from tools.infer_tools import DiffusionSVC
+    vw = Vocoder.__new__(Vocoder)
+    vw.vocoder, vw.vocoder_hop_size, vw.vocoder_sample_rate, vw.dimension, vw.device = voc, h["hop_size"], h["sampling_rate"], h["inter_channels"], dev
+    svc = DiffusionSVC(device=dev)
+    svc.model, svc.vocoder = model, vw
+    rag_rows = [torch.from_numpy((np.arange(n) * (7 + i) % 4096).astype(np.int64)).to(dev) for i, n in enumerate(range(272, 513, 16))]
+    rag_frames = sum(int(r.numel()) for r in rag_rows)
+
+    def ragged(streams):
+        keep["rag"] = infer_tts.synthesize_ragged(svc, codebook, rag_rows, 1, 1000 // args.nfe, args.method, streams=streams)
+    rag = {}
+    for name, lat, streams in (("sequential", False, 1), ("sequential_latency_mode", True, 1), ("streams4", False, 4), ("streams4_latency_mode", True, 4)):
+        unet.set_latency_mode(lat)
+        try:
+            rag[name + "_ms"] = 1e3 * timeit(lambda: ragged(streams), 1)
+        finally:
+            unet.set_latency_mode(False)
+    assert all(bool(torch.isfinite(w_).all()) for _, w_ in keep["rag"])
+    extra["ragged16_tokens_to_wav"] = {
+        "workload": f"{len(rag_rows)} utterances of {len(rag_rows)} different lengths (272 .. 512 frames, {rag_frames} in all): units -> {args.nfe}-step {args.method} "
+                    "-> HiFi-VAEGAN, one bucket per length (bit-identical with each utterance alone); streams4 = buckets overlapped on 4 HIP streams / host threads",
+        **rag, "best_x_realtime": rag_frames * FRAME_SEC / (min(rag.values()) * 1e-3),
     }
     # ---- the 22_infer_tts.py caller itself: ONE utterance, phones -> tokens -> units -> mel -> wav ----
     p1, t1 = phones[:1].contiguous(), tones[:1].contiguous()

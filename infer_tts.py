@@ -118,21 +118,25 @@ def text2semantic_rows(lm, phones, tones, spk_id=1, max_length=1024, phone_lengt
     return rows
 
 
-def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None):
+def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None, streams=1):
     """Utterances of different lengths through the sampler and the vocoder: rows of equal length run as one batch, and because no kernel
     reduces across the batch axis (batch invariance) every utterance's mel / waveform is bit-identical to running it alone.
     token_rows: list of 1-D int64 tensors.  noise_fn(n_utt, T) -> x_T [n_utt,1,M,T] injects the start noise (tests); returns a list of
-    (mel [T,M], wav [T*hop]) in the order of `token_rows`."""
+    (mel [T,M], wav [T*hop]) in the order of `token_rows`.
+    streams > 1: the length buckets are spread over that many HIP streams (each with its own workspace, lds/native.py Workspace) and, unless
+    noise_fn is given, over as many host threads -- ctypes releases the GIL while a sampler call enqueues its ~12 k launches.  A bucket of
+    one or two utterances leaves most of the chip idle, so buckets overlap on the GPU; the results are the same tensors either way."""
     from lds import native
     out = [None] * len(token_rows)
     by_len = {}
     for i, r in enumerate(token_rows):
         by_len.setdefault(int(r.numel()), []).append(i)
-    for T, idx in sorted(by_len.items()):
+
+    def run_bucket(T, idx):
         if T == 0:
             for i in idx:
                 out[i] = (torch.empty(0, codebook.shape[1]), torch.empty(0))
-            continue
+            return
         tok = torch.stack([token_rows[i] for i in idx])
         units = native.gather_rows(codebook, tok)
         real = torch.randn
@@ -146,6 +150,42 @@ def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="d
         wav = svc.mel2wav(mel, None)
         for j, i in enumerate(idx):
             out[i] = (mel[j], wav[j, 0])
+
+    buckets = sorted(by_len.items(), key=lambda kv: -kv[0] * len(kv[1]))      # largest first
+    if streams <= 1 or len(buckets) <= 1:
+        for T, idx in sorted(by_len.items()):
+            run_bucket(T, idx)
+        return out
+    dev = codebook.device
+    cur = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(dev) for _ in range(min(streams, len(buckets)))]
+    for s_ in pool:
+        s_.wait_stream(cur)      # the inputs were produced on the caller's stream
+
+    with torch.cuda.stream(pool[0]):      # the first bucket on this thread: it creates whatever native handle does not exist yet
+        run_bucket(*buckets[0])
+    buckets = buckets[1:]
+
+    def worker(k):
+        with torch.cuda.stream(pool[k]):
+            for T, idx in buckets[k::len(pool)]:
+                run_bucket(T, idx)
+    if noise_fn is not None:      # the injected noise swaps torch.randn, a process-wide name: one host thread, several streams
+        for k in range(len(pool)):
+            worker(k)
+    else:
+        import threading
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(pool))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    for s_ in pool:
+        cur.wait_stream(s_)
+    for mel_wav in out:      # the caller's stream owns the results from here on
+        for t in mel_wav:
+            if t.is_cuda:
+                t.record_stream(cur)
     return out
 
 

@@ -121,16 +121,21 @@ def _host_tensor_table(state):
 
 
 class Workspace:
-    """A growable device scratch buffer owned by torch (one per handle; grown on demand)."""
+    """Growable device scratch owned by torch: one buffer per (handle, HIP stream), grown on demand.  The library's handles are immutable
+    after create, so calls on different streams may overlap as long as each has its own workspace (include/lds.h) -- which is what keying
+    the buffer by the current stream gives (infer_tts.synthesize_ragged runs length buckets on several streams)."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes, device):
         import torch
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self.buf
+        key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
 
 
 class UNet:

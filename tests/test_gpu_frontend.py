@@ -227,6 +227,32 @@ def test_ragged_batch_phones_to_wav_equals_utterances_alone():
         assert torch.equal(got[i][0], one[0][0]) and torch.equal(got[i][1], one[0][1])
 
 
+@pytest.mark.parametrize("threads", [False, True])
+def test_ragged_buckets_on_streams_equal_sequential(threads):
+    """synthesize_ragged(streams=3): the length buckets overlap on three HIP streams, each with its own workspace (and, without injected
+    noise, on three host threads); every utterance's mel and waveform are the tensors of the sequential run, bit for bit"""
+    import infer_tts
+    from lds import init_weights
+    svc, codebook, _ = infer_tts.synthetic_pipeline("cuda", 8)
+    lens = [40, 24, 40, 33, 17, 24, 56]
+    rows = [torch.from_numpy((np.arange(n) * (7 + i) % 4096).astype(np.int64)).cuda() for i, n in enumerate(lens)]
+    if threads:      # the start noise comes from torch's generator: seeded runs draw the same x_T only if the draws happen in the same order,
+        # so compare the deterministic part -- a run whose noise is injected -- on one host thread, and here only check completion + shapes
+        got = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", streams=3)
+        torch.cuda.synchronize()
+        for (mel, wav), n in zip(got, lens):
+            assert mel.shape == (n, 80) and wav.shape == (n * 512,) and bool(torch.isfinite(mel).all()) and bool(torch.isfinite(wav).all())
+        return
+
+    def noise(idx_list, T):
+        return torch.stack([torch.from_numpy(init_weights.uniform(f"streams.xT.{i}", (1, 80, T), 3, -1.7, 1.7)) for i in idx_list]).cuda()
+    seq = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise)
+    par = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise, streams=3)
+    torch.cuda.synchronize()
+    for a, b in zip(seq, par):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_roformer_generate_bench_size_vs_oracle(lm_gpu):
     """Parity where the bench runs (VERDICT r2 #4b): 8 utterances x 64 phones -> 512 SAMPLED tokens (max_length 513: KV length, rotary
     positions and the key-split decode attention over the whole range) token-exact against oracle.roformer.generate, per-step logits 2e-5."""
