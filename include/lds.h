@@ -92,6 +92,17 @@ int lds_sampler_run(lds_unet* u, int method, int n_rows, const float* table, con
                     void* stream);
 int lds_sampler_workspace_bytes(const lds_unet* u, int B, int T, size_t* out);
 
+/* Ragged batches (the reference's 22_infer_tts.py:76-114 synthesises sentences of different lengths; a padded torch batch would change
+ * every GroupNorm statistic and attention row): `lengths` (host int32 [B], 1 <= lengths[b] <= T, B <= 64) are the utterances' own frame
+ * counts inside buffers of T frames.  Every kernel stops an utterance's statistics and attention keys at its length and writes zeros
+ * beyond it (the convolutions' zero padding, as when the utterance runs alone), and the decoder resamples every utterance to its own skip
+ * lengths.  Frames [0, lengths[b]) of utterance b equal the utterance run alone at its own length within the stated tolerances (not bit
+ * for bit: tile shapes follow the buffer length); frames beyond are unspecified in x / zero in eps.  Exact-fp32 GEMM mode only. */
+int lds_unet_forward_ragged(lds_unet* u, const float* x, const float* cond, const float* t, const int32_t* lengths, float* eps, void* ws,
+                            size_t ws_bytes, int B, int T, void* stream);
+int lds_sampler_run_ragged(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x, const float* noise,
+                           const int32_t* lengths, void* ws, size_t ws_bytes, int B, int T, void* stream);
+
 /* ---- front end: Unit2Mel.forward's condition (reference diffusion/unit2mel.py:79-82) ---------
  * cond[b,:,t] = unit_embed(units[b,t,:]) + spk_embed[spk_id[b]-1]                               */
 int lds_embed_create(int input_channel, int n_hidden, int n_spk, const float* unit_w,

@@ -97,7 +97,7 @@ static __device__ __forceinline__ void att_issue_tile(const __amdgpu_buffer_rsrc
 // staged tile, so twice as many waves share the work; the partial (max, sum, output) triples meet through LDS at the end.
 template <int D, int NW, int NST, int KS, bool F16>
 __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ out,
-                                                                int C, int T, float scale2, int out_bf3) {
+                                                                int C, int Tbuf, float scale2, int out_bf3, const int* __restrict__ lens, int lvl) {
     using Cfg = AttCfg<D, NW, NST, KS>;
     constexpr int NWQ = NW / KS;
     constexpr int KB = Cfg::KB, DQ = Cfg::DQ, DT = Cfg::DT, KPW = Cfg::KPW, VPW = Cfg::VPW, STAGE = Cfg::STAGE, PER_TILE = Cfg::PER_TILE;
@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     const int qblk = L % gx, hd = (L / gx) % gy, b = L / (gx * gy);
     const int qw = wave % NWQ, ks = wave / NWQ;       // query tile of this wave; which 32-key half of each tile it takes
     const int tq = qblk * (NWQ * 32) + qw * 32 + c;
-    const int Tp = T + 2, T4 = (T + 3) & ~3;
+    // T = this utterance's own length (ragged batches: keys stop there, queries beyond it are written as zeros); the strides are the buffer's
+    const int T = ragged_len(lens, b, lvl, Tbuf);
+    const int Tp = Tbuf + 2, T4 = (Tbuf + 3) & ~3;
     const float* qb = qk + ((long long)b * 2 * C + (long long)hd * D) * Tp;            // q rows of this head
 
     // queries: B operands, pre-multiplied by log2(e)/sqrt(d) so the scores come out in log2 units
@@ -331,7 +333,8 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
                     if (tq == T - 1) *reinterpret_cast<k8_u32x2*>(e + 16) = k8_u32x2{0u, 0u};
                 }
             }
-    } else if (tq < T) {
+    } else if (tq < Tbuf) {
+        const bool live = tq < T;      // (ragged batch: queries beyond the utterance's length are written as zeros)
         const float rl = 1.0f / l;
         float* ob = out + (long long)b * C * Tp;
 #pragma unroll
@@ -343,16 +346,16 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const long long off = ((long long)(q * 2 + hh) * Tp + tq + 1) * 4 + 2 * h;
-                    k4p_store_wt(ob + off, f32x2{o[i][4 * g + hh] * rl, o[i][4 * g + 2 + hh] * rl});      // write-through (k4p.h)
+                    k4p_store_wt(ob + off, live ? f32x2{o[i][4 * g + hh] * rl, o[i][4 * g + 2 + hh] * rl} : f32x2{0.f, 0.f});      // write-through (k4p.h)
                     if (tq == 0) *reinterpret_cast<f32x2*>(ob + off - 4) = f32x2{0.f, 0.f};
-                    if (tq == T - 1) *reinterpret_cast<f32x2*>(ob + off + 4) = f32x2{0.f, 0.f};
+                    if (tq == Tbuf - 1) *reinterpret_cast<f32x2*>(ob + off + 4) = f32x2{0.f, 0.f};
                 }
             }
     }
 }
 
 template <int D, int NW, int NST, int KS, bool F16>
-static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, int out_bf3, hipStream_t s) {
+static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, float scale, int out_bf3, const int* lens, int lvl, hipStream_t s) {
     using Cfg = AttCfg<D, NW, NST, KS>;
     auto kern = attention_k4p_kernel<D, NW, NST, KS, F16>;
     if (Cfg::LDS_BYTES > 48 * 1024) {
@@ -362,13 +365,13 @@ static hipError_t launch_cfg(const float* qk, const float* vt, float* out, int B
     }
     constexpr int QPB = NW / KS * 32;       // queries per workgroup
     hipEvent_t e0, e1;
-    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, e0, e1, 0, qk, vt, out, C, T, scale, out_bf3);
-    else hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale, out_bf3);
+    if (prof_attach_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, e0, e1, 0, qk, vt, out, C, T, scale, out_bf3, lens, lvl);
+    else hipLaunchKernelGGL(kern, dim3((T + QPB - 1) / QPB, heads, B), dim3(NW * 64), Cfg::LDS_BYTES, s, qk, vt, out, C, T, scale, out_bf3, lens, lvl);
     return hipGetLastError();
 }
 
 template <int D, bool F16>
-static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, int tile_batch, hipStream_t s) {
+static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, int tile_batch, const int* lens, int lvl, hipStream_t s) {
     const float scale = 1.4426950408889634f / sqrtf((float)D);    // log2(e) / sqrt(d)
     constexpr int NST = (D == 64) ? 2 : 3;
     // judged at the nominal per-GPU batch (16): the choice fixes the summation order, which must not depend on the batch size
@@ -376,37 +379,39 @@ static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B,
     const long long hb = (long long)heads * (tile_batch > 0 ? tile_batch : 16);
     // 128 queries per workgroup (four waves share each K/V tile) when that gives every CU two workgroups; for shorter
     // sequences 64 queries with the keys of each tile split over two wave groups; 32-query single-tile case last
-    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    if ((long long)((T + 127) / 128) * hb >= 512) return launch_cfg<D, 4, NST, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, lens, lvl, s);
     // latency mode, few (batch, head) pairs: 32 queries per workgroup, the keys' 32-key chunks round-robin over its four waves
     // (and a ring deep enough to have every K / V tile of the level's sequence in flight at once: with one workgroup per CU the tiles'
     //  DMA round trips, ~1 us each when taken two at a time, are what a short launch consists of; 144 / 123 / 128 KB of LDS)
     constexpr int NSTL = (D == 32) ? 9 : (D == 48) ? 5 : 4;
-    if (tile_batch > 0 && T > 64 && (long long)((T + 63) / 64) * hb < 256) return launch_cfg<D, 4, NSTL, 4, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
-    if (T > 32) return launch_cfg<D, 4, NST, 2, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
-    return launch_cfg<D, 1, 2, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, s);
+    if (tile_batch > 0 && T > 64 && (long long)((T + 63) / 64) * hb < 256) return launch_cfg<D, 4, NSTL, 4, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, lens, lvl, s);
+    if (T > 32) return launch_cfg<D, 4, NST, 2, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, lens, lvl, s);
+    return launch_cfg<D, 1, 2, 1, F16>(qk, vt, out, B, C, T, heads, scale, out_bf3, lens, lvl, s);
 }
 
 // math_f16: the two products on the fp16 matrix pipe with operands split in registers (the split-fp16 GEMM mode); else exact fp32
-static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, bool math_f16, int tile_batch, hipStream_t s) {
+static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, bool math_f16, int tile_batch, hipStream_t s,
+                                const int* lens = nullptr, int lvl = 0) {
+    if (lens && (out_bf3 || math_f16)) return hipErrorInvalidValue;      // per-utterance lengths: exact-fp32 path only
     if (C % heads) return hipErrorInvalidValue;
     ProfScope ps(s, math_f16 ? "attention_f16" : "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
     if (math_f16) {
         switch (C / heads) {
-            case 32: return launch_dk<32, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
-            case 48: return launch_dk<48, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
-            case 64: return launch_dk<64, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
+            case 32: return launch_dk<32, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, lens, lvl, s);
+            case 48: return launch_dk<48, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, lens, lvl, s);
+            case 64: return launch_dk<64, true>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, lens, lvl, s);
             default: return hipErrorInvalidValue;
         }
     }
     switch (C / heads) {
-        case 32: return launch_dk<32, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
-        case 48: return launch_dk<48, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
-        case 64: return launch_dk<64, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, s);
+        case 32: return launch_dk<32, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, lens, lvl, s);
+        case 48: return launch_dk<48, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, lens, lvl, s);
+        case 64: return launch_dk<64, false>(qk, vt, out, B, C, T, heads, out_bf3, tile_batch, lens, lvl, s);
         default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch) {
-    return attention_any(qk, vt, out, B, C, T, heads, 0, false, tile_batch, s);
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch, const int* lens, int lvl) {
+    return attention_any(qk, vt, out, B, C, T, heads, 0, false, tile_batch, s, lens, lvl);
 }
 hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt, int tile_batch) {
     return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, tile_batch, s);

@@ -252,8 +252,8 @@ struct Bf3Kernel {
     }
     __device__ __forceinline__ void gnf_request() {      // kernel start, before the first DMA
         const int G_ = p.gnf_groups, gsz = p.Ci / G_;
-        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0);
-        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0);
+        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0, p.Tsrc);
+        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0, p.Tsrc);
         if ((int)threadIdx.x < BM) {
             const int m = m0 + (int)threadIdx.x;
             gkc = p.gnf_c2[m];
@@ -270,7 +270,7 @@ struct Bf3Kernel {
             float rs = 1.f, sd = 1.f, rm = 0.f;
             if (g < G_) {
                 float mu, var;
-                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var);
+                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, p.Tsrc);
                 sd = sqrtf(var + p.gnf_eps); rs = 1.0f / sd; rm = rs * mu;
             }
             if (lane == 0) { tail[g] = rs; tail[8 + g] = sd; tail[16 + g] = rm; }
@@ -905,6 +905,7 @@ static hipError_t split_dispatch(const DmaConvArgs& a_, int cfg, int nprod, hipS
     DmaConvArgs a = a_;
     a.ksplit = 1;
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 32 || a.B <= 0 || a.To <= 0 || a.pad < 0 || a.pad > 1 || a.voc) return hipErrorInvalidValue;
+    if (a.lens) return hipErrorInvalidValue;      // per-utterance lengths are built for the exact-fp32 kernels only
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     int bm, bn, bk, nst;
     bf3_pick(a, cfg, bm, bn, bk, nst, FMT);

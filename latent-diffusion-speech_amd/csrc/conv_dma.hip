@@ -103,6 +103,7 @@ struct DmaKernel {
     float* smem;
     int lane, wave, c, h, wm, wn, ks, b, m0, t0;
     int ksp, kc0, ctile;      // cluster split-K (DmaConvArgs::ksplit): this workgroup's share index, its first K-step, its tile's linear index
+    int Lout;                 // valid output frames of this batch element (ragged batches, k4p.h ragged_len; = To otherwise)
     float gcg[GNF ? 8 : 1], gkc;      // (threads < BM: the terms of their row's constant, in flight across the first barrier)
     GnPart gp0, gp1;                  // this wave's two groups' partial statistics, in flight across the first DMAs
     float gs, gsn, ginv;              // rstd of the group of this wave's share of the current / the next K-step; 1 / (channels per group)
@@ -149,6 +150,7 @@ struct DmaKernel {
         kc0 = ksp * (p.Ci / BK / S);
         ctile = (b * nN + nb) * nMb + mb;
         m0 = mb * BM; t0 = nb * BN;
+        Lout = ragged_len(p.lens, b, p.lvl_out, p.To);
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int q = (wave + 4 * i) * 64 + lane;           // chunk = (tap, k-row, m)
@@ -311,9 +313,10 @@ struct DmaKernel {
     // partials (wave w takes groups w and w + 4) and for the terms of the row constants
     __device__ __forceinline__ void gnf_request() {
         const int G_ = p.gnf_groups, gsz = p.Ci / G_;
+        const int gTv = ragged_len(p.lens, b, p.lvl_in, p.Tsrc);      // the statistics stop at the utterance's own length
         ginv = 1.0f / (float)gsz;
-        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0);                              // (8 groups at most: wave < G_ or an unused slot)
-        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0);
+        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0, gTv);                              // (8 groups at most: wave < G_ or an unused slot)
+        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0, gTv);
         if ((int)threadIdx.x < BM) {
             const int m = m0 + (int)threadIdx.x;
             gkc = p.gnf_c2[m];
@@ -331,7 +334,7 @@ struct DmaKernel {
             float rs = 1.f, rm = 0.f;      // (slots of absent groups: finite, they multiply zeros)
             if (g < G_) {
                 float mu, var;
-                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var);
+                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
                 rs = 1.0f / sqrtf(var + p.gnf_eps); rm = rs * mu;
             }
             if (lane == 0) { tail[g] = rs; tail[8 + g] = rm; }
@@ -633,11 +636,11 @@ struct DmaKernel {
                 a1 += d0; a2 = fmaf(d0, d0, a2);
                 b1 += d1; b2 = fmaf(d1, d1, b2);
             }
-            if (!ok) { a1 = 0.f; a2 = 0.f; b1 = 0.f; b2 = 0.f; }
+            if (n >= Lout) { a1 = 0.f; a2 = 0.f; b1 = 0.f; b2 = 0.f; }      // (Lout <= To: frames beyond the utterance's length carry no statistics)
             a1 = wave_sum_to_lane63(a1); a2 = wave_sum_to_lane63(a2);
             b1 = wave_sum_to_lane63(b1); b2 = wave_sum_to_lane63(b2);
             const int n0 = n - c;                                   // first frame of this 32-frame block
-            const int nv = (p.To - n0 < 32) ? p.To - n0 : 32;       // valid frames
+            const int nv = (Lout - n0 < 32) ? Lout - n0 : 32;       // valid frames
             if (lane == 63 && nv > 0) {
                 const float cnt = 16.0f * (float)nv, rc = 1.0f / cnt;
                 float2* gp = p.gnpart_out + ((long long)b * (Ck >> 4) + (tile0 >> 4)) * ((p.To + 31) >> 5) + (n0 >> 5);
@@ -766,6 +769,18 @@ struct DmaKernel {
                         const int tile0 = tile_ch(i, geglu);
                         if (tile0 < p.Cout) add_running_sum(tile0, i, j, t0 + wn * TN * 32 + j * 32 + c);
                     }
+            }
+        } else {
+            if (p.lens) {      // ragged batch: frames at and beyond this utterance's length are written as zeros, in whatever layout
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (t0 + wn * TN * 32 + j * 32 + c >= Lout) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[0][i][j][r] = 0.f;
+                    }
+                }
             }
         }
 #pragma unroll

@@ -31,24 +31,27 @@ static __device__ __forceinline__ void chan_step(float& n, float& mean, float& m
 // between the request and the use: gn_part_load = this lane's partial of round p0 (an empty one beyond the group's last),
 // gn_group_finish = the combination (further rounds are loaded there; P <= 64 partials -- every level of the UNet -- need none).
 struct GnPart { float n, mean, m2; };
-static __device__ __forceinline__ GnPart gn_part_load(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, int p0) {
+// Tv: valid frames of this batch element (ragged batches; = T otherwise): blocks beyond it are empty partials whatever the buffer holds
+static __device__ __forceinline__ GnPart gn_part_load(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, int p0, int Tv) {
     const int nT = (T + 31) >> 5, P = cg16 * nT;
     const int pi = p0 + lane;
     GnPart r{0.f, 0.f, 0.f};
     if (pi < P) {
         const int kk = (int)(((float)pi + 0.5f) * (1.0f / (float)nT)), tb = pi - kk * nT, kb = g * cg16 + kk;      // pi / nT without the integer-division sequence
-        const float2 pr = gp[((long long)b * (C >> 4) + kb) * nT + tb];
-        const int nv = (T - tb * 32 < 32) ? T - tb * 32 : 32;
-        r.n = 16.0f * (float)nv; r.mean = pr.x; r.m2 = pr.y;
+        const int nv = (Tv - tb * 32 < 32) ? Tv - tb * 32 : 32;
+        if (nv > 0) {
+            const float2 pr = gp[((long long)b * (C >> 4) + kb) * nT + tb];
+            r.n = 16.0f * (float)nv; r.mean = pr.x; r.m2 = pr.y;
+        }
     }
     return r;
 }
-static __device__ __forceinline__ void gn_group_finish(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, GnPart first, float& mu, float& var) {
+static __device__ __forceinline__ void gn_group_finish(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, GnPart first, float& mu, float& var, int Tv) {
     const int nT = (T + 31) >> 5, P = cg16 * nT;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     chan(n, mean, m2, first.n, first.mean, first.m2);
     for (int p0 = 64; p0 < P; p0 += 64) {
-        const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0);
+        const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0, Tv);
         chan(n, mean, m2, q.n, q.mean, q.m2);
     }
     chan_step<0x111, 0xf, true>(n, mean, m2);

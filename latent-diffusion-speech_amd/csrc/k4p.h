@@ -28,4 +28,15 @@ static __device__ __forceinline__ void k4p_store_wt(float* p, k4p_f32x2 v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Ragged batches: lens[b] = valid frames of utterance b at the UNet's input resolution (device int32 [B]; nullptr = every utterance has the
+// buffer's length T).  Level l of the UNet halves a length l times the way its stride-2 convolutions do.  Frames at and beyond an
+// utterance's length hold zeros in every activation tensor -- they are the convolutions' zero padding, exactly as when the utterance
+// runs alone -- so every kernel that writes a tensor writes zeros there, and GroupNorm statistics / attention keys stop at the length.
+static __device__ __forceinline__ int ragged_len(const int* lens, int b, int lvl, int T) {
+    if (!lens) return T;
+    int n = lens[b];
+    for (int i = 0; i < lvl; ++i) n = (n - 1) / 2 + 1;
+    return n < T ? n : T;
+}
+
 }  // namespace lds

@@ -19,25 +19,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // one workgroup per (b, 8-channel block)
-__global__ void __launch_bounds__(256) to_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int Ctot, int c_off) {
+__global__ void __launch_bounds__(256) to_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T, int Ctot, int c_off, const int* __restrict__ lens) {
     const int q = blockIdx.x, b = blockIdx.y;
-    const int Tp = T + 2;
+    const int Tp = T + 2, Tv = ragged_len(lens, b, 0, T);      // (ragged batch: zeros from the utterance's length on)
     float* ob = out + (((long long)b * (Ctot >> 3) + (c_off >> 3) + q) * 2) * Tp * 4;
     const float* ib = in + ((long long)b * C + q * 8) * T;
     for (int idx = threadIdx.x; idx < 2 * Tp; idx += 256) {
         const int hh = idx / Tp, e = idx - hh * Tp, t = e - 1;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < T) {
+        if (t >= 0 && t < Tv) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ib[(long long)(2 * j + hh) * T + t];
         }
         *reinterpret_cast<f32x4*>(ob + (long long)idx * 4) = v;
     }
 }
-hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
+hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, const int* lens) {
     if ((C & 7) || (Ctot & 7) || (c_off & 7)) return hipErrorInvalidValue;
     ProfScope ps(s, "to_k4p", 0.0, 8.0 * B * (double)C * T);
-    hipLaunchKernelGGL(to_k4p_kernel, dim3(C / 8, B), dim3(256), 0, s, in, out, C, T, Ctot, c_off);
+    hipLaunchKernelGGL(to_k4p_kernel, dim3(C / 8, B), dim3(256), 0, s, in, out, C, T, Ctot, c_off, lens);
     return hipGetLastError();
 }
 
@@ -187,8 +187,10 @@ template <int E>
 __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1, int C2, int T,
                                                         int groups, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ ss, int ss_stride, int ss_off, int silu,
-                                                        const float2* __restrict__ gp1, const float2* __restrict__ gp2, float* __restrict__ y) {
+                                                        const float2* __restrict__ gp1, const float2* __restrict__ gp2, float* __restrict__ y,
+                                                        const int* __restrict__ lens, int lvl) {
     const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int Tv = ragged_len(lens, b, lvl, T);      // ragged batch: statistics over, and output for, the utterance's own frames; zeros beyond
     const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
     const float* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * 2) * Tp * 4 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * 2) * Tp * 4;
     float* yb = y + (((long long)b * nq + q) * 2) * Tp * 4;
@@ -231,9 +233,11 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
         float nb = 0.f, mb = 0.f, qb = 0.f;
         if (pi < P) {
             const int kk = (int)(((float)pi + 0.5f) * inv_nT), tb = pi - kk * nT, kb = g * cg16 + kk;      // pi / nT without the integer-division sequence
-            const float2 pr = (kb < nk1) ? gp1[((long long)b * nk1 + kb) * nT + tb] : gp2[((long long)b * (C2 >> 4) + (kb - nk1)) * nT + tb];
-            const int nv = (T - tb * 32 < 32) ? T - tb * 32 : 32;
-            nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
+            const int nv = (Tv - tb * 32 < 32) ? Tv - tb * 32 : 32;
+            if (nv > 0) {
+                const float2 pr = (kb < nk1) ? gp1[((long long)b * nk1 + kb) * nT + tb] : gp2[((long long)b * (C2 >> 4) + (kb - nk1)) * nT + tb];
+                nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
+            }
         }
         chan(n, mean, m2, nb, mb, qb);
     }
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
                 for (int j = 0; j < 4; ++j) {
                     float r = (v[i][j] - mu) * (hh ? ga[1][j] : ga[0][j]) + (hh ? be[1][j] : be[0][j]);
                     if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                    o[j] = r;
+                    o[j] = (t < Tv) ? r : 0.f;
                 }
                 // write-through 16-byte store (sc1): no dirty lines left for the end-of-kernel write-back (k4p.h, k4p_store_wt)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)(((long long)hh * Tp + t + 1) * 16), 0, 16);
@@ -288,13 +292,13 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
 
 hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                             const float* beta, const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2,
-                            float* y, int B, hipStream_t s) {
+                            float* y, int B, hipStream_t s, const int* lens, int lvl) {
     const int C = C1 + C2;
     if ((C1 & 15) || (C2 & 15) || groups <= 0 || C % groups || (C / groups) % 16 || !gp1 || (C2 && !gp2)) return hipErrorInvalidValue;
     ProfScope ps(s, "gn_stream", 0.0, 4.0 * 2.0 * B * (double)C * T, true);
     const dim3 grid(C / 8, B), blk(256);
     const int need = (2 * T + 255) / 256;
-#define GN_ARGS x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2 ? gp2 : gp1, y
+#define GN_ARGS x1, x2 ? x2 : x1, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2 ? gp2 : gp1, y, lens, lvl
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) {      // bench.py's instrumented step: the events ride in the dispatch
         if (need <= 1) hipExtLaunchKernelGGL(gn_stream_kernel<1>, grid, blk, 0, s, e0, e1, 0, GN_ARGS);
@@ -307,24 +311,28 @@ hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, in
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) resample_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int Tin, int Tout) {
+__global__ void __launch_bounds__(256) resample_k4p_kernel(const float* __restrict__ in, float* __restrict__ out, int Tin, int Tout, int rows_per_b,
+                                                           const int* __restrict__ lens, int lvl_in, int lvl_out) {
     const long long row = blockIdx.x;                // (b, q, hh) flattened
-    const float sc = (float)Tin / (float)Tout;
+    const int b = (int)(row / rows_per_b);
+    // ragged batch: every utterance is resampled from ITS input length to ITS output length (F.interpolate(size=) of the utterance alone)
+    const int Ti = ragged_len(lens, b, lvl_in, Tin), To = ragged_len(lens, b, lvl_out, Tout);
+    const float sc = (float)Ti / (float)To;
     const float* ib = in + row * (Tin + 2) * 4;
     float* ob = out + row * (Tout + 2) * 4;
     for (int e = threadIdx.x; e < Tout + 2; e += 256) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (e >= 1 && e <= Tout) {
+        if (e >= 1 && e <= To) {
             int src = (int)floorf((float)(e - 1) * sc);
-            if (src > Tin - 1) src = Tin - 1;
+            if (src > Ti - 1) src = Ti - 1;
             v = *reinterpret_cast<const f32x4*>(ib + (long long)(src + 1) * 4);
         }
         *reinterpret_cast<f32x4*>(ob + (long long)e * 4) = v;
     }
 }
-hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s) {
+hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s, const int* lens, int lvl_in, int lvl_out) {
     ProfScope ps(s, "resample", 0.0, 4.0 * B * (double)C * (Tin + Tout));
-    hipLaunchKernelGGL(resample_k4p_kernel, dim3((unsigned)((long long)B * C / 4)), dim3(256), 0, s, in, out, Tin, Tout);
+    hipLaunchKernelGGL(resample_k4p_kernel, dim3((unsigned)((long long)B * C / 4)), dim3(256), 0, s, in, out, Tin, Tout, C / 4, lens, lvl_in, lvl_out);
     return hipGetLastError();
 }
 

@@ -107,6 +107,9 @@ struct DmaConvArgs {
     // batch and an utterance's result is bit-identical for any batch split.  > 0 (lds_unet_set_latency_mode): the actual batch, so that
     // one or two utterances spread over the chip -- same tolerances against the oracle, not bit-identical with batched results.
     int tile_batch;
+    // Ragged batches (k4p.h ragged_len): per-utterance lengths at the UNet's input resolution and the levels of this launch's input and
+    // output tensors; output frames at and beyond an utterance's length are written as zeros.  nullptr: no masking.
+    const int* lens; int lvl_in, lvl_out;
     // Cluster split-K (latency mode only; conv_dma.hip cluster_join): ksplit = S > 1 workgroups share an output tile, each reducing 1/S
     // of the K-steps; kpart = scratch for the partial tiles (tiles x 4 waves x S x 1024 floats), kcount = one zeroed counter per
     // (tile, wave), left zeroed.  The launchers choose S (conv_dma_cluster_split) when tile_batch > 0 and kpart / kcount are given.
@@ -150,7 +153,7 @@ hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin
 // K4P helpers (k4p_ops.hip)
 // ---------------------------------------------------------------------------------------------
 // plain [B][C][T] -> channels [c_off, c_off+C) of a K4P tensor with Ctot channels (pads of those rows zeroed)
-hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s);
+hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, const int* lens = nullptr);
 hipError_t launch_from_k4p(const float* in, float* out, int B, int C, int T, hipStream_t s);
 hipError_t launch_from_k4p_pad(const float* in, float* out, int B, int C, int T, int pad, hipStream_t s);
 // plain [B][C][T] -> attention's VT layout [B][C/D][ceil(T/4)][D][4] (tail keys zeroed); the UNet gets this layout straight
@@ -164,7 +167,7 @@ hipError_t launch_plain_to_vt(const float* in, float* out, int B, int C, int T, 
 // while the tensor loads are in flight.
 hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps,
                             const float* gamma, const float* beta, const float* scale_shift, int ss_stride, int ss_off,
-                            int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s);
+                            int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s, const int* lens = nullptr, int lvl = 0);
 // the same partials computed from a K4P tensor by a stand-alone pass (tensors not produced by conv_dma; test entry points)
 hipError_t launch_gn_partials(const float* x, int C, int T, float2* gp, int B, hipStream_t s);
 // nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
@@ -172,11 +175,13 @@ hipError_t launch_gn_partials(const float* x, int C, int T, float2* gp, int B, h
 hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s);
 // zero the `pad` frames on both sides of every row of a K4P tensor (tensors whose writers only store real frames)
 hipError_t launch_k4p_zero_pads(float* x, int B, int C, int T, int pad, hipStream_t s);
-hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s);
+// lens: per-utterance lengths (ragged_len) at levels lvl_in / lvl_out of the two tensors
+hipError_t launch_resample_k4p(const float* in, float* out, int B, int C, int Tin, int Tout, hipStream_t s, const int* lens = nullptr, int lvl_in = 0, int lvl_out = 0);
 // self-attention: q,k in K4P (tensor qk [B][2C][T]: q channels 0..C-1, k channels C..2C-1), v in the VT layout
 // [B][heads][ceil(T/4)][D][4] (key tail zeroed); out K4P [B][C][T]
 // tile_batch: as DmaConvArgs::tile_batch (0 = nominal batch of 16)
-hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0);
+hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0,
+                                const int* lens = nullptr, int lvl = 0);
 // the same with the output written as a K8B3 tensor (split-bf16 path: the output feeds the to_out projection)
 hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0);
 hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0, int tile_batch = 0);

@@ -475,11 +475,19 @@ struct DOpt {
     const float2* ln_part = nullptr; int ln_np = 0; float ln_eps = 1e-5f; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
     const float2* gnf_part = nullptr; int gnf_groups = 0; float gnf_eps = 1e-5f; const float* gnf_cg = nullptr; const float* gnf_c2 = nullptr;   // GroupNorm fold
     int cfg = 0;
+    int lvl_in = 0, lvl_out = 0;      // ragged batches: UNet levels of the input / output tensors (k4p.h ragged_len)
     int out_f32 = 0;      // split-bf16 path: the K4P-range output channels stay fp32 K4P (q / k for the attention kernel)
 };
 // Batch size the launchers judge their tile / split choices at while a UNet call of this thread is running: 0 = the nominal batch (the
 // default: results do not depend on the batch split), the actual batch in latency mode (lds_unet_set_latency_mode).
 static std::atomic<int> g_gn_fold{1};      // lds_debug_set_gn_fold: 0 = the transformer's GroupNorm as its own pass (A/B measurements, tests)
+// per-utterance lengths of the ragged batch a UNet call of this thread is running on (device int32 [B]; null = none): k4p.h ragged_len
+static thread_local const int* tl_lens = nullptr;
+struct LensScope {
+    const int* prev;
+    explicit LensScope(const int* l) : prev(tl_lens) { tl_lens = l; }
+    ~LensScope() { tl_lens = prev; }
+};
 static thread_local int tl_tile_batch = 0;
 // ... and the scratch of the latency mode's cluster split-K (kernels.h DmaConvArgs::ksplit): partial tiles + arrival counters
 constexpr long long kClusterPartFloats = 4ll << 20;      // 16 MB: 320 workgroups x 4 waves x 1024 floats = 1.3 M floats are ever in use
@@ -497,6 +505,7 @@ struct TileBatchScope {
 static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, DmaConvArgs& a) {
     memset(&a, 0, sizeof(a));
     a.tile_batch = tl_tile_batch;
+    a.lens = tl_lens; a.lvl_in = o.lvl_in; a.lvl_out = o.lvl_out;
     a.kpart = tl_kpart; a.kcount = tl_kcount; a.kpart_cap = kClusterPartFloats; a.kcount_cap = kClusterCounters;
     if (C1 + C2 != W.Ci) return fail(LDS_EINVAL, "dconv: input channels %d+%d != %d", C1, C2, W.Ci);
     a.x1 = x1; a.x2 = x2 ? x2 : x1; a.C1 = C1; a.C2 = C2; a.Tsrc = Tsrc;
@@ -579,13 +588,15 @@ static int run_dconv_bf3(const ConvW& W, const void* x1, int C1, const void* x2,
 // conv2 (k 3 over h) and the 1x1 shortcut (over the block input x1 ; x2) of a resnet in one launch: out = W2 * h + Ws * [x1 ; x2] + bias.
 // Returns 1 when there is no fused variant for these shapes (the caller then runs the two convolutions separately).
 static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, const float* x1, int C1, const float* x2, int C2, int T, const float* bias_pair,
-                          float2* gnpart_out, float* out, int B, hipStream_t st) {
+                          float2* gnpart_out, float* out, int B, hipStream_t st, int lvl = 0) {
     DmaConvArgs a3, a1;
     DOpt o3;
+    o3.lvl_in = o3.lvl_out = lvl;
     o3.pad = 1;
     int rc = fill_dconv(W3, h, W3.Ci, nullptr, 0, T, o3, out, B, a3);
     if (rc != LDS_OK) return rc;
     DOpt o1;
+    o1.lvl_in = o1.lvl_out = lvl;
     o1.gnpart_out = gnpart_out;
     rc = fill_dconv(W1, x1, C1, x2, C2, T, o1, out, B, a1);
     if (rc != LDS_OK) return rc;
@@ -661,12 +672,12 @@ static int dconv_any(int mode, const ConvW& W, const float* x1, int C1, const fl
     return mode ? run_dconv_bf3(W, x1, C1, x2, C2, Tsrc, o, out, B, st, 0, mode - 1) : run_dconv(W, x1, C1, x2, C2, Tsrc, o, out, B, st);
 }
 static hipError_t gn_any(int mode, const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma, const float* beta,
-                         const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s) {
+                         const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s, int lvl = 0) {
     return mode ? launch_gn_stream_bf3(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, mode - 1)
-                : launch_gn_stream(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s);
+                : launch_gn_stream(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, tl_lens, lvl);
 }
 static hipError_t to_act_any(int mode, const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
-    return mode ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s, mode - 1) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s);
+    return mode ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s, mode - 1) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s, tl_lens);
 }
 
 // ================================================================================================
@@ -1020,6 +1031,7 @@ struct UnetWs {
     float *e1, *emb, *tproj;
     float2* lnp;
     float* kpart; unsigned* kcount;      // latency mode: cluster split-K scratch (partial tiles, arrival counters)
+    int* lens_dev;                       // ragged batches: the per-utterance lengths (<= 64 utterances)
     float* xin;
     float *xk, *ck, *cinc;      // sampler runs: the sample alone in K4P, the condition alone, conv_in's condition half (+ bias), computed once per run
     std::vector<float*> skips;
@@ -1095,6 +1107,7 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     w.gno = A.f(B * maxgn);
     w.qk = A.f(B * maxatt * 2); w.v = A.f(B * (maxatt + 2048)); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
     w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2);
+    w.lens_dev = (int*)A.f(64);
     w.kpart = u->latency_mode ? A.f(kClusterPartFloats) : nullptr;
     w.kcount = u->latency_mode ? (unsigned*)A.f(kClusterCounters) : nullptr;
     A.f(16384);   // tail slack: ragged last tiles read (masked) entries past a tensor's end
@@ -1110,38 +1123,42 @@ extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t*
 }
 
 static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, const float* x1, int C1, const float* x2, int C2, int T,
-                      float* out, int B, hipStream_t st) {
+                      float* out, int B, hipStream_t st, int lvl = 0) {
     // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut.
     // GroupNorm(+scale/shift)+SiLU is materialised once per tensor by a streaming pass (gn_stream) so the convolutions stay
     // VALU-free; its statistics come from the partials the producers of x1 / x2 / h1 wrote in their epilogues.
     const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
-    HIP_TRY(gn_any(bf3, x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.gp(x1), x2 ? w.gp(x2) : nullptr, w.gno, B, st));
+    HIP_TRY(gn_any(bf3, x1, x2, C1, C2, T, u->G, 1e-5f, r.g1, r.b1, nullptr, 0, 0, 1, w.gp(x1), x2 ? w.gp(x2) : nullptr, w.gno, B, st, lvl));
     DOpt o1;
+    o1.lvl_in = o1.lvl_out = lvl;
     o1.pad = 1; o1.gnpart_out = w.gp(w.h1);
     LDS_TRY(dconv_any(bf3, r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
-    HIP_TRY(gn_any(bf3, w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr, w.gno, B, st));
+    HIP_TRY(gn_any(bf3, w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr, w.gno, B, st, lvl));
     const float* res = x1;
     if (r.has_sc) {
         // the shortcut rides in conv2's launch (second reduction into the same accumulators; skip-concat on read: two source pointers)
         const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, bf3 - 1)
-                           : run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st);
+                           : run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, lvl);
         if (rc != 1) return rc;
         DOpt os;      // no fused variant for these shapes: two launches
+        os.lvl_in = os.lvl_out = lvl;
         LDS_TRY(dconv_any(bf3, r.sc, x1, C1, x2, C2, T, os, w.sc, B, st));
         res = w.sc;
     }
     DOpt o2;
+    o2.lvl_in = o2.lvl_out = lvl;
     o2.pad = 1; o2.res = res; o2.gnpart_out = w.gp(out);
     return dconv_any(bf3, r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
 }
 
-static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st) {
+static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st, int lvl = 0) {
     // reference transformer_1d.py:256-295 + attention.py:130-203, kept channel-major (K4P).  Every conv that feeds a
     // LayerNorm also emits per-32-channel (mean, M2) partials per frame; the consumer (QKV / FF1) combines them per column and
     // applies the LayerNorm in its epilogue (weights pre-multiplied by gamma, pack_ln_fold).
     const int bf3 = u->gemm_mode;      // 0 = fp32; else split planes, format bf3 - 1
     const int C = t.C;
     DOpt op;
+    op.lvl_in = op.lvl_out = lvl;
     op.lnpart_out = w.lnp;
     if (t.fold && g_gn_fold.load(std::memory_order_relaxed)) {
         // proj_in(GroupNorm(x)) in one launch: the statistics come from the partials x's producer wrote, the normalisation is a rescaling
@@ -1149,31 +1166,50 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         op.gnf_part = w.gp(x); op.gnf_groups = u->G; op.gnf_eps = 1e-6f; op.gnf_cg = t.pi_cg; op.gnf_c2 = t.pi_c2;
         LDS_TRY(dconv_any(bf3, t.proj_in_g, x, C, nullptr, 0, T, op, w.ta, B, st));
     } else {
-        HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st));
+        HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st, lvl));
         LDS_TRY(dconv_any(bf3, t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
     }
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
         DOpt oq;
+        oq.lvl_in = oq.lvl_out = lvl;
         oq.plain_from = 2 * C; oq.out2 = w.v; oq.vt_D = C / u->heads;      // q, k in K4P; v in attention's VT layout
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
         oq.out_f32 = bf3 ? 1 : 0;                                          // (split-bf16 mode: q / k / v stay fp32 for the attention kernel)
         LDS_TRY(dconv_any(bf3, t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
         if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1, tl_tile_batch));
-        else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st, tl_tile_batch));
+        else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st, tl_tile_batch, tl_lens, lvl));
         DOpt oo;
+        oo.lvl_in = oo.lvl_out = lvl;
         oo.res = h; oo.lnpart_out = w.lnp;
         LDS_TRY(dconv_any(bf3, t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
         float* tmp = h; h = hn; hn = tmp;
     }
     DOpt of;
+    of.lvl_in = of.lvl_out = lvl;
     of.epi = EPI_GEGLU;
     of.ln_part = w.lnp; of.ln_np = C / 32; of.ln_c1 = t.ff1_c1; of.ln_c2 = t.ff1_c2;
     LDS_TRY(dconv_any(bf3, t.ff1, h, C, nullptr, 0, T, of, w.ff, B, st));
     DOpt o2;      // ff.net.2 + residual + proj_out + residual in one launch (load_tfm: ff2_out)
+    o2.lvl_in = o2.lvl_out = lvl;
     o2.res = x; o2.gnpart_out = w.gp(out);
     return dconv_any(bf3, t.ff2_out, w.ff, 4 * C, h, C, T, o2, out, B, st);
+}
+
+// Ragged batches: per-utterance lengths (host int32 [B], 1 <= len <= T; null = none) -> the workspace's device copy, carried in a launch's
+// kernel arguments (<= 64 utterances).  Split GEMM modes have no masked kernels.
+static int ragged_len_host(int n, int lvl) { for (int i = 0; i < lvl; ++i) n = (n - 1) / 2 + 1; return n; }
+static int upload_lens(const lds_unet* u, const int* lens_host, int B, int T, int* dev, hipStream_t st) {
+    if (u->gemm_mode != LDS_GEMM_F32) return fail(LDS_EINVAL, "per-utterance lengths are built for the exact-fp32 GEMM mode");
+    if (B > 64) return fail(LDS_EINVAL, "per-utterance lengths: at most 64 utterances per call (got %d)", B);
+    float tmp[64];
+    for (int b = 0; b < B; ++b) {
+        if (lens_host[b] < 1 || lens_host[b] > T) return fail(LDS_EINVAL, "length[%d] = %d outside 1 .. %d", b, lens_host[b], T);
+        memcpy(&tmp[b], &lens_host[b], sizeof(int));
+    }
+    HIP_TRY(launch_set_list((float*)dev, tmp, B, st));
+    return LDS_OK;
 }
 
 // uniform_t: every batch element shares t[0] (the samplers' case) -> the time-embedding path runs for one column and
@@ -1187,11 +1223,13 @@ static int time_embedding(const lds_unet* u, const float* t, float* e1, float* e
 }
 
 // the condition is the same for every evaluation of a sampler run: its channels of the K4P input tensor are written once
-static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_bytes, int B, int T, hipStream_t st) {
+static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_bytes, int B, int T, hipStream_t st, const int* lens_host = nullptr) {
     Arena A(ws, ws_bytes);
     UnetWs w;
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
+    if (lens_host) LDS_TRY(upload_lens(u, lens_host, B, T, w.lens_dev, st));
+    LensScope lsc(lens_host ? w.lens_dev : nullptr);
     TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
     if (u->latency_mode) HIP_TRY(launch_fill((float*)w.kcount, 0.f, kClusterCounters, st));      // (bit pattern 0 = counter 0)
     // conv_in is linear in its input channels: the condition's contribution (and the bias) is the same for every evaluation of the run.
@@ -1208,11 +1246,15 @@ static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_b
 // cond_staged: the condition channels of the input tensor were already converted by unet_stage_cond
 static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
                              int B, int T, hipStream_t st, bool uniform_t = false, const float* tproj_pre = nullptr,
-                             bool cond_staged = false) {
+                             bool cond_staged = false, const int* lens_host = nullptr) {
     Arena A(ws, ws_bytes);
     UnetWs w;
     plan_ws(u, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
+    // ragged batch: the lengths reach the device once per call (per run when the sampler staged them with the condition)
+    if (lens_host && !cond_staged) LDS_TRY(upload_lens(u, lens_host, B, T, w.lens_dev, st));
+    if (lens_host && u->gemm_mode != LDS_GEMM_F32) return fail(LDS_EINVAL, "per-utterance lengths are built for the exact-fp32 GEMM mode");
+    LensScope lsc(lens_host ? w.lens_dev : nullptr);
     TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
     // the counters are left at zero by every launch that uses them; a forward starts from zeroed ones whatever the workspace held before
     if (u->latency_mode && !cond_staged) HIP_TRY(launch_fill((float*)w.kcount, 0.f, kClusterCounters, st));
@@ -1244,31 +1286,33 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
         LDS_TRY(dconv_any(bf3, u->conv_in, w.xin, cin, nullptr, 0, T, o, w.skips[si], B, st));
     }
     const float* cur = w.skips[si++];
-    int Tl = T;
+    int Tl = T, lvl = 0;      // lvl: how many stride-2 convolutions lie between the input and this resolution (ragged batches, k4p.h)
     std::vector<int> skipT{T};
     for (int i = 0; i < nb; ++i) {
         const DownBlk& d = u->down[i];
         for (size_t j = 0; j < d.res.size(); ++j) {
             float* dst = w.skips[si];
             const bool att = !d.att.empty();
-            LDS_TRY(run_resnet(u, d.res[j], w, cur, d.res[j].cin, nullptr, 0, Tl, att ? w.r : dst, B, st));
-            if (att) LDS_TRY(run_tfm(u, d.att[j], w, w.r, Tl, dst, B, st));
+            LDS_TRY(run_resnet(u, d.res[j], w, cur, d.res[j].cin, nullptr, 0, Tl, att ? w.r : dst, B, st, lvl));
+            if (att) LDS_TRY(run_tfm(u, d.att[j], w, w.r, Tl, dst, B, st, lvl));
             cur = dst;
             ++si;
             skipT.push_back(Tl);
         }
         if (d.has_down) {
             DOpt o;
+            o.lvl_in = lvl; o.lvl_out = lvl + 1;
             o.pad = 1; o.stride = 2; o.gnpart_out = w.gp(w.skips[si]);
             LDS_TRY(dconv_any(bf3, d.down, cur, d.ch, nullptr, 0, Tl, o, w.skips[si], B, st));
             Tl = down_len(Tl);
+            ++lvl;
             cur = w.skips[si++];
             skipT.push_back(Tl);
         }
     }
-    LDS_TRY(run_resnet(u, u->mid_r0, w, cur, u->mid_r0.cin, nullptr, 0, Tl, w.cur[0], B, st));
-    LDS_TRY(run_tfm(u, u->mid_t, w, w.cur[0], Tl, w.cur[1], B, st));
-    LDS_TRY(run_resnet(u, u->mid_r1, w, w.cur[1], u->mid_r1.cin, nullptr, 0, Tl, w.cur[0], B, st));
+    LDS_TRY(run_resnet(u, u->mid_r0, w, cur, u->mid_r0.cin, nullptr, 0, Tl, w.cur[0], B, st, lvl));
+    LDS_TRY(run_tfm(u, u->mid_t, w, w.cur[0], Tl, w.cur[1], B, st, lvl));
+    LDS_TRY(run_resnet(u, u->mid_r1, w, w.cur[1], u->mid_r1.cin, nullptr, 0, Tl, w.cur[0], B, st, lvl));
     cur = w.cur[0];
     int ci = 0;  // index of the buffer `cur` lives in
     for (int i = 0; i < nb; ++i) {
@@ -1280,8 +1324,8 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             const int hin = b.res[j].cin - b.skip_ch[j];
             const bool att = !b.att.empty();
             float* dst = w.cur[ci ^ 1];
-            LDS_TRY(run_resnet(u, b.res[j], w, cur, hin, skip, b.skip_ch[j], Tl, att ? w.r : dst, B, st));
-            if (att) LDS_TRY(run_tfm(u, b.att[j], w, w.r, Tl, dst, B, st));
+            LDS_TRY(run_resnet(u, b.res[j], w, cur, hin, skip, b.skip_ch[j], Tl, att ? w.r : dst, B, st, lvl));
+            if (att) LDS_TRY(run_tfm(u, b.att[j], w, w.r, Tl, dst, B, st, lvl));
             cur = dst;
             ci ^= 1;
         }
@@ -1291,21 +1335,28 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             float* dst = w.cur[ci ^ 1];
             DOpt o;
             o.pad = 1; o.gnpart_out = w.gp(dst);
-            if (Tn == 2 * Tl) {
+            o.lvl_in = o.lvl_out = lvl - 1;
+            // ragged batch: the on-read doubling needs EVERY utterance's target length to be twice its own length at this level
+            bool doubles = Tn == 2 * Tl;
+            if (lens_host)
+                for (int ub = 0; ub < B; ++ub) doubles = doubles && ragged_len_host(lens_host[ub], lvl - 1) == 2 * ragged_len_host(lens_host[ub], lvl);
+            if (doubles) {
+                o.lvl_in = lvl;
                 o.ups = 1;
                 LDS_TRY(dconv_any(bf3, b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
             } else {
-                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st, bf3 - 1) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st));
+                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st, bf3 - 1) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st, tl_lens, lvl, lvl - 1));
                 LDS_TRY(dconv_any(bf3, b.up, w.upt, b.ch, nullptr, 0, Tn, o, dst, B, st));
             }
             Tl = Tn;
+            --lvl;
             cur = dst;
             ci ^= 1;
         }
     }
     // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031); eps leaves in the caller's frame-major layout
     const int c0 = u->cfg.block_out_channels[0];
-    HIP_TRY(gn_any(bf3, cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.gp(cur), nullptr, w.gno, B, st));
+    HIP_TRY(gn_any(bf3, cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.gp(cur), nullptr, w.gno, B, st, 0));
     DOpt o;
     o.pad = 1; o.out_plain = 1;
     return dconv_any(bf3, u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st);
@@ -1315,6 +1366,11 @@ extern "C" int lds_unet_forward(lds_unet* u, const float* x, const float* cond, 
                                 int B, int T, void* stream) {
     if (!u || !x || !cond || !t || !eps || !ws || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
     return unet_forward_impl(u, x, cond, t, eps, ws, ws_bytes, B, T, (hipStream_t)stream);
+}
+extern "C" int lds_unet_forward_ragged(lds_unet* u, const float* x, const float* cond, const float* t, const int32_t* lengths, float* eps, void* ws,
+                                       size_t ws_bytes, int B, int T, void* stream) {
+    if (!u || !x || !cond || !t || !lengths || !eps || !ws || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    return unet_forward_impl(u, x, cond, t, eps, ws, ws_bytes, B, T, (hipStream_t)stream, false, nullptr, false, lengths);
 }
 
 // ================================================================================================
@@ -1343,8 +1399,19 @@ extern "C" int lds_sampler_workspace_bytes(const lds_unet* u, int B, int T, size
     return LDS_OK;
 }
 
+static int sampler_run_impl(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x, const float* noise, void* ws, size_t ws_bytes,
+                            int B, int T, void* stream, const int* lens);
 extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x,
                                const float* noise, void* ws, size_t ws_bytes, int B, int T, void* stream) {
+    return sampler_run_impl(u, method, n_rows, table, cond, x, noise, ws, ws_bytes, B, T, stream, nullptr);
+}
+extern "C" int lds_sampler_run_ragged(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x, const float* noise,
+                                      const int32_t* lengths, void* ws, size_t ws_bytes, int B, int T, void* stream) {
+    if (!lengths) return fail(LDS_EINVAL, "bad argument");
+    return sampler_run_impl(u, method, n_rows, table, cond, x, noise, ws, ws_bytes, B, T, stream, lengths);
+}
+static int sampler_run_impl(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x, const float* noise, void* ws, size_t ws_bytes,
+                            int B, int T, void* stream, const int* lens) {
     if (!u || !table || !cond || !x || !ws || n_rows <= 0 || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     ProfChain chain;
@@ -1367,15 +1434,15 @@ extern "C" int lds_sampler_run(lds_unet* u, int method, int n_rows, const float*
         HIP_TRY(launch_set_list(s.tp_t, tlist.data(), (int)tlist.size(), st));      // in the launch's arguments: no pageable async copy
         LDS_TRY(time_embedding(u, s.tp_t, s.tp_e1, s.tp_emb, s.tp_proj, (int)tlist.size(), st));
     }
-    LDS_TRY(unet_stage_cond(u, cond, uws, uws_bytes, B, T, st));
+    LDS_TRY(unet_stage_cond(u, cond, uws, uws_bytes, B, T, st, lens));
     auto model = [&](const float* xin, float t_in) -> int {
         if (pre) {
             for (size_t i = 0; i < tlist.size(); ++i)
                 if (tlist[i] == t_in)
-                    return unet_forward_impl(u, xin, cond, nullptr, s.eps, uws, uws_bytes, B, T, st, true, s.tp_proj + i * u->tp_M, true);
+                    return unet_forward_impl(u, xin, cond, nullptr, s.eps, uws, uws_bytes, B, T, st, true, s.tp_proj + i * u->tp_M, true, lens);
         }
         HIP_TRY(launch_fill(s.tvec, t_in, B, st));
-        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st, true, nullptr, true);
+        return unet_forward_impl(u, xin, cond, s.tvec, s.eps, uws, uws_bytes, B, T, st, true, nullptr, true, lens);
     };
     float *m0 = s.m0, *m1 = s.m1, *m2 = s.m2;
     if (method == LDS_METHOD_DPM_SOLVER_PP) {

@@ -246,6 +246,15 @@ class GaussianDiffusion(nn.Module):
                             float(self._buf("sqrt_one_minus_alphas_cumprod")[ti]))
 
     def forward(self, condition, gt_spec=None, infer=True, infer_speedup=10, method="dpm-solver", k_step=None, use_tqdm=False):
+        return self._sample(condition, gt_spec, infer, infer_speedup, method, k_step, None)
+
+    def forward_ragged(self, condition, lengths, gt_spec=None, infer_speedup=10, method="dpm-solver", k_step=None):
+        """Extension (not in the reference): a RAGGED batch in one call.  condition [B, T, H] padded to the longest utterance, lengths [B] the
+        utterances' own frame counts; every utterance is sampled as if it ran alone at its own length (include/lds.h lds_sampler_run_ragged);
+        frames of the result beyond an utterance's length are zeros."""
+        return self._sample(condition, gt_spec, True, infer_speedup, method, k_step, lengths)
+
+    def _sample(self, condition, gt_spec, infer, infer_speedup, method, k_step, lengths):
         if not infer:
             raise NotImplementedError("training (p_losses) is out of scope for the MI355X sampler build")
         if not condition.is_cuda:
@@ -267,16 +276,16 @@ class GaussianDiffusion(nn.Module):
                 # multistep order 2: the reference solvers assert this (dpm_solver_pytorch.py:1172, uni_pc.py:607)
                 assert t // infer_speedup >= 2, f"steps = {t} // {infer_speedup} must be >= order 2"
             if method == "dpm-solver":
-                unet.sample("dpm-solver", self._table(("dpm", t, infer_speedup), lambda: dpm_table(self._buf("betas")[:t], t // infer_speedup)), cond, x)
+                unet.sample("dpm-solver", self._table(("dpm", t, infer_speedup), lambda: dpm_table(self._buf("betas")[:t], t // infer_speedup)), cond, x, lengths=lengths)
             elif method == "unipc":
-                unet.sample("unipc", self._table(("unipc", t, infer_speedup), lambda: unipc_table(self._buf("betas")[:t], t // infer_speedup)), cond, x)
+                unet.sample("unipc", self._table(("unipc", t, infer_speedup), lambda: unipc_table(self._buf("betas")[:t], t // infer_speedup)), cond, x, lengths=lengths)
             elif method == "pndm":
                 if b != 1:
                     # reference diffusion.py:155 `max(t - interval, 0)` on a batch tensor raises for B > 1
                     raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous")
-                unet.sample("pndm", self._table(("plms", t, infer_speedup), lambda: self._plms_table(t, infer_speedup)), cond, x)
+                unet.sample("pndm", self._table(("plms", t, infer_speedup), lambda: self._plms_table(t, infer_speedup)), cond, x, lengths=lengths)
             elif method == "ddim":
-                unet.sample("ddim", self._table(("ddim", t, infer_speedup), lambda: self._ddim_table(t, infer_speedup)), cond, x)
+                unet.sample("ddim", self._table(("ddim", t, infer_speedup), lambda: self._ddim_table(t, infer_speedup)), cond, x, lengths=lengths)
             else:
                 raise NotImplementedError(method)
         else:
@@ -286,6 +295,10 @@ class GaussianDiffusion(nn.Module):
                 n = min(chunk, t - s0)
                 # one randn per step in the reference's draw order (diffusion.py:118)
                 noise = torch.stack([torch.randn(shape, device=device) for _ in range(n)]).reshape(n, b, self.out_dims, -1)
-                unet.sample("ddpm", tab[s0:s0 + n], cond, x, noise.contiguous())
+                unet.sample("ddpm", tab[s0:s0 + n], cond, x, noise.contiguous(), lengths=lengths)
         # x.squeeze(1).transpose(1, 2) / acoustic_scale  (reference diffusion.py:342-343)
-        return native.transpose(x, float(self.acoustic_scale))
+        mel = native.transpose(x, float(self.acoustic_scale))
+        if lengths is not None:      # the sampler's state beyond an utterance's length is the scaled start noise: not part of the result
+            ln = torch.as_tensor(lengths, device=mel.device).reshape(-1, 1)
+            mel = mel * (torch.arange(mel.shape[1], device=mel.device)[None, :] < ln)[:, :, None]
+        return mel

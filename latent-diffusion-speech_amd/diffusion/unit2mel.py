@@ -97,6 +97,14 @@ class Unit2Mel(nn.Module):
 
     def forward(self, units, volume, spk_id=None, aug_shift=None, gt_spec=None, infer=True, infer_speedup=10, method="unipc",
                 use_tqdm=False):
+        return self._forward(units, volume, spk_id, aug_shift, gt_spec, infer, infer_speedup, method, None)
+
+    def forward_ragged(self, units, lengths, spk_id=None, infer_speedup=10, method="unipc"):
+        """Extension (not in the reference): units [B, T, C] padded to the longest utterance + the utterances' own frame counts -> mel
+        [B, T, M] with zeros beyond each length; every utterance as if it ran alone (GaussianDiffusion.forward_ragged)."""
+        return self._forward(units, None, spk_id, None, None, True, infer_speedup, method, lengths)
+
+    def _forward(self, units, volume, spk_id, aug_shift, gt_spec, infer, infer_speedup, method, lengths):
         # reference unit2mel.py:74-77: volume_embed is None, so a non-None volume cannot be embedded there either
         if volume is not None:
             raise NotImplementedError("volume_embed is None in the reference (unit2mel.py:55); pass volume=None")
@@ -117,4 +125,6 @@ class Unit2Mel(nn.Module):
         # x = unit_embed(units) + spk_embed(spk_id - 1), produced channel-major by liblds
         cond = self._native_embed().forward(units.contiguous().float(), spk_id)        # [B,H,T]
         x = native.transpose(cond)                                                     # [B,T,H] as the reference hands over
-        return self.decoder(x, gt_spec=gt_spec, infer=infer, infer_speedup=infer_speedup, method=method, use_tqdm=use_tqdm)
+        if lengths is not None:
+            return self.decoder.forward_ragged(x, lengths, gt_spec=gt_spec, infer_speedup=infer_speedup, method=method)
+        return self.decoder(x, gt_spec=gt_spec, infer=infer, infer_speedup=infer_speedup, method=method, use_tqdm=False)

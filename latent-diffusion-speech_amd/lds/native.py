@@ -51,7 +51,7 @@ EXPORTS = [
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_gather_rows", "lds_resample_frames", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_lm_create", "lds_lm_destroy", "lds_lm_workspace_bytes", "lds_lm_encode",
     "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_unet_set_gemm_mode", "lds_unet_get_gemm_mode",
-    "lds_unet_set_latency_mode", "lds_unet_get_latency_mode"]
+    "lds_unet_set_latency_mode", "lds_unet_get_latency_mode", "lds_unet_forward_ragged", "lds_sampler_run_ragged"]
 # include/lds_test.h: single-op entry points for tests/ and tools/ (not part of the drop-in boundary)
 TEST_EXPORTS = [
     "lds_test_conv", "lds_test_dconv", "lds_bench_dconv", "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p",
@@ -175,7 +175,15 @@ class UNet:
     def latency_mode(self):
         return int(lib().lds_unet_get_latency_mode(self.h))
 
-    def forward(self, x, cond, t):
+    @staticmethod
+    def _lengths(lengths, B, T):
+        """per-utterance frame counts of a ragged batch -> host int32 [B] (include/lds.h lds_sampler_run_ragged)"""
+        a = np.ascontiguousarray(np.asarray(lengths.cpu() if hasattr(lengths, "cpu") else lengths).reshape(-1), dtype=np.int32)
+        if a.shape != (B,) or a.min() < 1 or a.max() > T:
+            raise ValueError(f"lengths must be {B} integers in 1 .. {T}")
+        return a
+
+    def forward(self, x, cond, t, lengths=None):
         import torch
         B, M, T = x.shape
         assert M == self.M and cond.shape == (B, self.H, T) and t.shape == (B,)
@@ -183,12 +191,18 @@ class UNet:
         check(lib().lds_unet_workspace_bytes(self.h, B, T, C.byref(nb)))
         ws = self.ws.get(nb.value, x.device)
         eps = torch.empty_like(x)
+        if lengths is not None:
+            ln = self._lengths(lengths, B, T)
+            check(lib().lds_unet_forward_ragged(self.h, _dev(x, torch.float32), _dev(cond, torch.float32), _dev(t, torch.float32), C.c_void_p(ln.ctypes.data),
+                                                _dev(eps), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
+            return eps
         check(lib().lds_unet_forward(self.h, _dev(x, torch.float32), _dev(cond, torch.float32), _dev(t, torch.float32),
                                      _dev(eps), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
         return eps
 
-    def sample(self, method, table, cond, x, noise=None):
-        """Run a whole sampler loop in place on x [B,M,T]; table: float32 [n_rows, 16] (host)."""
+    def sample(self, method, table, cond, x, noise=None, lengths=None):
+        """Run a whole sampler loop in place on x [B,M,T]; table: float32 [n_rows, 16] (host); lengths: the utterances' own frame counts
+        (ragged batch) or None."""
         import torch
         B, M, T = x.shape
         table = np.ascontiguousarray(table, dtype=np.float32)
@@ -196,9 +210,14 @@ class UNet:
         nb = C.c_size_t()
         check(lib().lds_sampler_workspace_bytes(self.h, B, T, C.byref(nb)))
         ws = self.ws.get(nb.value, x.device)
+        nz = _dev(noise, torch.float32) if noise is not None else None
+        if lengths is not None:
+            ln = self._lengths(lengths, B, T)
+            check(lib().lds_sampler_run_ragged(self.h, METHODS[method], table.shape[0], C.c_void_p(table.ctypes.data), _dev(cond, torch.float32),
+                                               _dev(x, torch.float32), nz, C.c_void_p(ln.ctypes.data), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
+            return x
         check(lib().lds_sampler_run(self.h, METHODS[method], table.shape[0], C.c_void_p(table.ctypes.data),
-                                    _dev(cond, torch.float32), _dev(x, torch.float32),
-                                    _dev(noise, torch.float32) if noise is not None else None, _dev(ws),
+                                    _dev(cond, torch.float32), _dev(x, torch.float32), nz, _dev(ws),
                                     C.c_size_t(ws.numel()), B, T, _stream()))
         return x
 

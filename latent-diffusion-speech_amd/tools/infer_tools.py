@@ -49,6 +49,13 @@ class DiffusionSVC:
                           infer_speedup=infer_speedup, method=method, use_tqdm=use_tqdm)
 
     @torch.no_grad()
+    def call_ragged(self, units, lengths, spk_id=1, infer_speedup=10, method="unipc"):
+        """Extension: a padded ragged batch of units [B,T,C] + per-utterance frame counts -> mel [B,T,M] (Unit2Mel.forward_ragged)"""
+        B = units.shape[0]
+        sid = spk_id.to(self.device).long().reshape(B, -1) if torch.is_tensor(spk_id) else torch.LongTensor(np.full((B, 1), int(spk_id))).to(self.device)
+        return self.model.forward_ragged(units.to(self.device), lengths, spk_id=sid, infer_speedup=infer_speedup, method=method)
+
+    @torch.no_grad()
     def infer(self, units, f0=None, volume=None, gt_spec=None, spk_id=1, aug_shift=0, infer_speedup=10, method="unipc", use_tqdm=True):
         """reference infer_tools.py:77-81: units -> waveform [B,1,T*hop]"""
         out_mel = self.__call__(units, f0, volume, spk_id=spk_id, aug_shift=aug_shift, gt_spec=None, infer_speedup=infer_speedup,

@@ -434,3 +434,75 @@ def test_latency_sampler_bench_size_vs_oracle(unit2mel_latency, unet_weights, mo
     f = o_u2m.make_eps_fn(w, cfg, blocks, np.ascontiguousarray(cond.transpose(0, 2, 1)))
     ref = oracle_once(("bench512", "dpm-solver"), lambda: solvers.sample(f, schedule.diffusion_buffers(), xT[:, 0], "dpm-solver", 100))
     record_margin(relmax(y, np.ascontiguousarray(ref.transpose(0, 2, 1))), 1e-4)
+
+
+# ---- ragged batches in one call (lds_unet_forward_ragged / lds_sampler_run_ragged): per-utterance lengths inside buffers of T frames ----
+@pytest.fixture(scope="module")
+def unit2mel_f32():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from diffusion.unit2mel import Unit2Mel
+    m = Unit2Mel(1280, 323, 80)
+    m.to("cuda").eval()
+    return m
+
+
+@pytest.mark.parametrize("T,lens,latency", [(77, [77, 50, 33], False), (512, [512, 300, 272, 401], False), (130, [64, 130, 7, 129, 2], False),
+                                            (512, [301, 512], True), (200, [200] * 3, False)])
+def test_ragged_unet_forward_vs_alone(unit2mel_f32, unet_weights, T, lens, latency, record_margin):
+    """every utterance of a padded batch against the same utterance evaluated alone at its own length (odd lengths at every level: the
+    decoder resamples each utterance to its own skip lengths; lengths 2 and 7: levels of one frame); zeros beyond each length"""
+    from lds import init_weights
+    unet = unit2mel_f32.decoder.denoise_fn
+    unet.set_latency_mode(latency)
+    try:
+        B = len(lens)
+        x = init_weights.uniform(f"rag.{T}.{B}", (B, 336, T), 61, -2, 2)
+        t = np.linspace(40.5, 873.25, B).astype(np.float32)
+        dx, dt_ = dev(x), dev(t)
+        got = unet.native().forward(dx[:, :80].contiguous(), dx[:, 80:].contiguous(), dt_, lengths=lens)
+        assert torch.isfinite(got).all()
+        worst = 0.0
+        for b, n in enumerate(lens):
+            alone = unet(dx[b:b + 1, :, :n].contiguous(), dt_[b:b + 1]).sample
+            worst = max(worst, relmax(got[b:b + 1, :, :n].cpu().numpy(), alone.cpu().numpy()))
+            assert float(got[b, :, n:].abs().max()) == 0.0 if n < T else True
+        record_margin(worst, 2e-5)
+        if T == 77:      # and against the oracle itself for one utterance
+            from oracle import unet1d
+            cfg, blocks, w = unet_weights
+            ref = unet1d.unet_forward(w, cfg, blocks, x[1:2, :, :50], t[1:2])
+            record_margin(relmax(got[1:2, :, :50].cpu().numpy(), ref), 2e-5, "oracle")
+    finally:
+        unet.set_latency_mode(False)
+
+
+@pytest.mark.parametrize("method,speedup", [("dpm-solver", 250), ("unipc", 250), ("ddim", 250)])
+def test_ragged_sampler_vs_alone(unit2mel_f32, monkeypatch, method, speedup, record_margin):
+    """GaussianDiffusion.forward_ragged: a padded batch of three lengths through a 4-step run, every utterance against its own run alone"""
+    from lds import init_weights
+    gd = unit2mel_f32.decoder
+    T, lens = 96, [96, 61, 40]
+    B = len(lens)
+    cond = init_weights.uniform("rag.s.cond", (B, T, 256), 71, -1, 1)
+    xT = init_weights.uniform("rag.s.xT", (B, 1, 80, T), 72, -1.7, 1.7)
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: dev(xT))
+    y = gd.forward_ragged(dev(cond), lens, infer_speedup=speedup, method=method)
+    assert y.shape == (B, T, 80) and torch.isfinite(y).all()
+    worst = 0.0
+    for b, n in enumerate(lens):
+        monkeypatch.setattr(torch, "randn", lambda *a, **k: dev(np.ascontiguousarray(xT[b:b + 1, :, :, :n])))
+        alone = gd(dev(np.ascontiguousarray(cond[b:b + 1, :n])), infer=True, infer_speedup=speedup, method=method)
+        worst = max(worst, relmax(y[b:b + 1, :n].cpu().numpy(), alone.cpu().numpy()))
+        assert n == T or float(y[b, n:].abs().max()) == 0.0
+    record_margin(worst, 1e-4)
+
+
+def test_ragged_rejected_in_split_modes(unit2mel_f32):
+    unet = unit2mel_f32.decoder.denoise_fn
+    unet.set_gemm_mode("split_f16")
+    try:
+        x = torch.zeros(2, 336, 64, device="cuda")
+        with pytest.raises(RuntimeError, match="exact-fp32"):
+            unet.native().forward(x[:, :80].contiguous(), x[:, 80:].contiguous(), torch.zeros(2, device="cuda"), lengths=[64, 30])
+    finally:
+        unet.set_gemm_mode("f32")
