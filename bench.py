@@ -554,9 +554,15 @@ def extra_legs(args, dev, model, make_inputs):
         finally:
             unet.set_latency_mode(False)
     assert all(bool(torch.isfinite(w_).all()) for _, w_ in keep["rag"])
+
+    def ragged_masked():      # ONE padded sampler batch with per-utterance lengths in the kernels, vocoder by bucket on 4 streams
+        keep["ragm"] = infer_tts.synthesize_ragged_masked(svc, codebook, rag_rows, 1, 1000 // args.nfe, args.method, streams=4, max_batch=16)
+    rag["masked_batch_ms"] = 1e3 * timeit(ragged_masked, 1)
+    assert all(bool(torch.isfinite(w_).all()) for _, w_ in keep["ragm"])
     extra["ragged16_tokens_to_wav"] = {
         "workload": f"{len(rag_rows)} utterances of {len(rag_rows)} different lengths (272 .. 512 frames, {rag_frames} in all): units -> {args.nfe}-step {args.method} "
-                    "-> HiFi-VAEGAN, one bucket per length (bit-identical with each utterance alone); streams4 = buckets overlapped on 4 HIP streams / host threads",
+                    "-> HiFi-VAEGAN, one bucket per length (bit-identical with each utterance alone); streams4 = buckets overlapped on 4 HIP streams / host threads; "
+                    "masked_batch = the sampler as ONE padded batch with per-utterance lengths inside the kernels (lds_sampler_run_ragged; parity tolerance, not bit-identity)",
         **rag, "best_x_realtime": rag_frames * FRAME_SEC / (min(rag.values()) * 1e-3),
     }
     # ---- the 22_infer_tts.py caller itself: ONE utterance, phones -> tokens -> units -> mel -> wav ----

@@ -118,6 +118,70 @@ def text2semantic_rows(lm, phones, tones, spk_id=1, max_length=1024, phone_lengt
     return rows
 
 
+def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None, streams=1, max_batch=16):
+    """Utterances of different lengths with the SAMPLER run as one padded batch per `max_batch` rows and per-utterance lengths inside the
+    kernels (Unit2Mel.forward_ragged: every utterance as if it ran alone -- statistics, attention and resampling stop at its own length;
+    within the parity tolerances of the stand-alone run, not bit for bit), then the vocoder per length bucket (on `streams` HIP streams).
+    Rows are sorted by length so that a padded batch wastes few frames.  Returns [(mel [T,M], wav [T*hop])] in the order of `token_rows`."""
+    from lds import native
+    order = sorted((i for i, r in enumerate(token_rows) if r.numel() > 0), key=lambda i: -int(token_rows[i].numel()))
+    mels = [None] * len(token_rows)
+    for c0 in range(0, len(order), max_batch):
+        idx = order[c0:c0 + max_batch]
+        lens = [int(token_rows[i].numel()) for i in idx]
+        T = max(lens)
+        tok = torch.zeros(len(idx), T, dtype=torch.int64, device=codebook.device)
+        for j, i in enumerate(idx):
+            tok[j, :lens[j]] = token_rows[i]
+        units = native.gather_rows(codebook, tok)
+        real = torch.randn
+        if noise_fn is not None:
+            xT = torch.zeros(len(idx), 1, svc.model.decoder.out_dims, T, device=codebook.device)
+            for j, i in enumerate(idx):
+                xT[j:j + 1, :, :, :lens[j]] = noise_fn([i], lens[j])
+            torch.randn = lambda *a, **k: xT.clone()
+        try:
+            mel = svc.call_ragged(units, lens, spk_id=spk_id, infer_speedup=speedup, method=method)
+        finally:
+            torch.randn = real
+        for j, i in enumerate(idx):
+            mels[i] = mel[j, :lens[j]].contiguous()
+    # the vocoder has no normalisation across frames but its activations leak across a padded tail: per length bucket, as before
+    out = [None] * len(token_rows)
+    by_len = {}
+    for i, r in enumerate(token_rows):
+        by_len.setdefault(int(r.numel()), []).append(i)
+
+    def voc_bucket(T, idx):
+        if T == 0:
+            for i in idx:
+                out[i] = (torch.empty(0, codebook.shape[1]), torch.empty(0))
+            return
+        wav = svc.mel2wav(torch.stack([mels[i] for i in idx]), None)
+        for j, i in enumerate(idx):
+            out[i] = (mels[i], wav[j, 0])
+    buckets = sorted(by_len.items())
+    if streams <= 1 or len(buckets) <= 1:
+        for T, idx in buckets:
+            voc_bucket(T, idx)
+        return out
+    dev = codebook.device
+    cur = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(dev) for _ in range(min(streams, len(buckets)))]
+    for k, s_ in enumerate(pool):
+        s_.wait_stream(cur)
+        with torch.cuda.stream(s_):
+            for T, idx in buckets[k::len(pool)]:
+                voc_bucket(T, idx)
+    for s_ in pool:
+        cur.wait_stream(s_)
+    for mel_wav in out:
+        for t in mel_wav:
+            if t.is_cuda:
+                t.record_stream(cur)
+    return out
+
+
 def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None, streams=1):
     """Utterances of different lengths through the sampler and the vocoder: rows of equal length run as one batch, and because no kernel
     reduces across the batch axis (batch invariance) every utterance's mel / waveform is bit-identical to running it alone.

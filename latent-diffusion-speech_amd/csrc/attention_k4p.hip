@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
     for (int i = 0; i < KPW; ++i) koff[i] = (((wave + NW * i) * Tp) + lane + 1) * 16;
 #pragma unroll
     for (int i = 0; i < VPW; ++i) voff[i] = ((wave + NW * i) * 64 + lane) * 16;
-    const int nt = (T + KB - 1) / KB;
+    // (ragged batch: a query block wholly beyond the utterance's length attends to nothing; its zeros are written below)
+    const int nt = (qblk * (NWQ * 32) >= T) ? 0 : (T + KB - 1) / KB;
     for (int t = 0; t < NST - 1 && t < nt; ++t) att_issue_tile<D, NW, KPW, VPW>(rk, rv, koff, voff, wave, t, smem + t * STAGE);
 #pragma unroll
     for (int kq = 0; kq < DQ; ++kq) qv[kq] *= scale2;

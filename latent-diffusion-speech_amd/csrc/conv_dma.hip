@@ -175,6 +175,7 @@ struct DmaKernel {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
     }
+    __device__ __forceinline__ bool dead_tile() const { return !VOC && p.lens && t0 >= Lout; }
     __device__ __forceinline__ void setup() {
         setup_keep_acc();
 #pragma unroll
@@ -810,7 +811,9 @@ __global__ void __launch_bounds__(256, ((VOC && KT == 2) ? 2 : DmaCfg<BM, BN, KT
     extern __shared__ __attribute__((aligned(16))) float smem[];
     DmaKernel<BM, BN, KT, STRIDE, UPS, BK, NST, DIL, VOC, GNF> k(p, smem);
     k.setup();
-    k.mainloop();
+    // ragged batch: a tile that lies wholly beyond its utterance's length has nothing to reduce -- the epilogue writes its zeros (what it
+    // computes from the untouched accumulators never reaches memory: masked columns are stored as literal zeros)
+    if (!k.dead_tile()) k.mainloop();
     k.epilogue();
 }
 
@@ -837,7 +840,7 @@ __global__ void __launch_bounds__(256, (PairCfg<BM, BN, BK3, BK1, NST>::OCC)) co
     {
         K3 k3(pp.a3, smem);
         k3.setup();
-        k3.mainloop();
+        if (!k3.dead_tile()) k3.mainloop();
 #pragma unroll
         for (int a = 0; a < K3::NACC; ++a)
 #pragma unroll
@@ -847,7 +850,7 @@ __global__ void __launch_bounds__(256, (PairCfg<BM, BN, BK3, BK1, NST>::OCC)) co
     }
     __syncthreads();                // every wave is done reading the first phase's stages
     k1.setup_keep_acc();
-    k1.mainloop();
+    if (!k1.dead_tile()) k1.mainloop();
     k1.epilogue();
 }
 
