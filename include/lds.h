@@ -97,7 +97,7 @@ int lds_sampler_workspace_bytes(const lds_unet* u, int B, int T, size_t* out);
  * counts inside buffers of T frames.  Every kernel stops an utterance's statistics and attention keys at its length and writes zeros
  * beyond it (the convolutions' zero padding, as when the utterance runs alone), and the decoder resamples every utterance to its own skip
  * lengths.  Frames [0, lengths[b]) of utterance b equal the utterance run alone at its own length within the stated tolerances (not bit
- * for bit: tile shapes follow the buffer length); frames beyond are unspecified in x / zero in eps.  Exact-fp32 GEMM mode only. */
+ * for bit: tile shapes follow the buffer length); frames beyond are unspecified in x / zero in eps.  Every GEMM mode. */
 int lds_unet_forward_ragged(lds_unet* u, const float* x, const float* cond, const float* t, const int32_t* lengths, float* eps, void* ws,
                             size_t ws_bytes, int B, int T, void* stream);
 int lds_sampler_run_ragged(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x, const float* noise,

@@ -305,7 +305,8 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // own + partner (each appears once)
     }
-    if (tq < T && out_bf3) {
+    if (tq < Tbuf && out_bf3) {
+        const bool live = tq < T;      // (ragged batch: queries beyond the utterance's length are written as zero planes)
         // split-plane output (k8b3.h; the split-GEMM path's to_out projection reads it): rows 8g + 4h + e of a 32-row tile are channel
         // positions 4h + e of 8-channel block g -- this lane half's 8 bytes of each plane's 16-byte entry.  out_bf3: 1 = bf16x3, 2 = fp16x2
         const float rl = 1.0f / l;
@@ -329,9 +330,9 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
                 for (int pl = 0; pl < 3; ++pl) {
                     if (pl >= npl) break;
                     char* e = ob + ((((long long)b * (C >> 3) + q) * npl + pl) * Tp + tq + 1) * 16 + h * 8;
-                    k8_store_wt(e, k8_u32x2{pa[pl], pb[pl]});
+                    k8_store_wt(e, live ? k8_u32x2{pa[pl], pb[pl]} : k8_u32x2{0u, 0u});
                     if (tq == 0) *reinterpret_cast<k8_u32x2*>(e - 16) = k8_u32x2{0u, 0u};
-                    if (tq == T - 1) *reinterpret_cast<k8_u32x2*>(e + 16) = k8_u32x2{0u, 0u};
+                    if (tq == Tbuf - 1) *reinterpret_cast<k8_u32x2*>(e + 16) = k8_u32x2{0u, 0u};
                 }
             }
     } else if (tq < Tbuf) {
@@ -393,7 +394,6 @@ static hipError_t launch_dk(const float* qk, const float* vt, float* out, int B,
 // math_f16: the two products on the fp16 matrix pipe with operands split in registers (the split-fp16 GEMM mode); else exact fp32
 static hipError_t attention_any(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, int out_bf3, bool math_f16, int tile_batch, hipStream_t s,
                                 const int* lens = nullptr, int lvl = 0) {
-    if (lens && (out_bf3 || math_f16)) return hipErrorInvalidValue;      // per-utterance lengths: exact-fp32 path only
     if (C % heads) return hipErrorInvalidValue;
     ProfScope ps(s, math_f16 ? "attention_f16" : "attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * C * T, true);
     if (math_f16) {
@@ -414,8 +414,8 @@ static hipError_t attention_any(const float* qk, const float* vt, float* out, in
 hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch, const int* lens, int lvl) {
     return attention_any(qk, vt, out, B, C, T, heads, 0, false, tile_batch, s, lens, lvl);
 }
-hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt, int tile_batch) {
-    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, tile_batch, s);
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt, int tile_batch, const int* lens, int lvl) {
+    return attention_any(qk, vt, (float*)out, B, C, T, heads, fmt == FMT_F16X2 ? 2 : 1, fmt == FMT_F16X2, tile_batch, s, lens, lvl);
 }
 // test entry: K4P fp32 in and out, the products on the fp16 pipe
 hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch) {

@@ -103,6 +103,7 @@ struct Bf3Kernel {
     float* smem;
     int lane, wave, c, h, wm, wn, ks, b, m0, t0;
     int ksp, kc0, ctile;      // cluster split-K (latency mode; conv_dma.hip cluster_join): share index, first K-step, tile index
+    int Lout;                 // valid output frames of this batch element (ragged batches, k4p.h ragged_len; = To otherwise)
     // GroupNorm fold: (threads < BM) the terms of their row's constant, this wave's two groups' partial statistics (both in flight across
     // the first DMAs), the group of this wave's share of the current K-step and the share's channel offset inside it
     float gcg[GNF ? 8 : 1], gkc;
@@ -142,6 +143,7 @@ struct Bf3Kernel {
         kc0 = ksp * (p.Ci / BK / S);
         ctile = (b * nN + nb) * nMb + mb;
         m0 = mb * BM; t0 = nb * BN;
+        Lout = ragged_len(p.lens, b, p.lvl_out, p.To);
         constexpr int kOob = 0x40000000;      // beyond every buffer: the range check returns zeros
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
@@ -168,6 +170,7 @@ struct Bf3Kernel {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
     }
+    __device__ __forceinline__ bool dead_tile() const { return p.lens && t0 >= Lout; }
     __device__ __forceinline__ void setup() {
         setup_keep_acc();
 #pragma unroll
@@ -252,8 +255,8 @@ struct Bf3Kernel {
     }
     __device__ __forceinline__ void gnf_request() {      // kernel start, before the first DMA
         const int G_ = p.gnf_groups, gsz = p.Ci / G_;
-        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0, p.Tsrc);
-        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0, p.Tsrc);
+        gp0 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, wave, lane, 0, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
+        gp1 = gn_part_load(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, (wave + 4 < G_) ? wave + 4 : wave, lane, 0, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
         if ((int)threadIdx.x < BM) {
             const int m = m0 + (int)threadIdx.x;
             gkc = p.gnf_c2[m];
@@ -270,7 +273,7 @@ struct Bf3Kernel {
             float rs = 1.f, sd = 1.f, rm = 0.f;
             if (g < G_) {
                 float mu, var;
-                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, p.Tsrc);
+                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
                 sd = sqrtf(var + p.gnf_eps); rs = 1.0f / sd; rm = rs * mu;
             }
             if (lane == 0) { tail[g] = rs; tail[8 + g] = sd; tail[16 + g] = rm; }
@@ -581,11 +584,11 @@ struct Bf3Kernel {
                 a1 += d0; a2 = fmaf(d0, d0, a2);
                 b1 += d1; b2 = fmaf(d1, d1, b2);
             }
-            if (!ok) { a1 = 0.f; a2 = 0.f; b1 = 0.f; b2 = 0.f; }
+            if (n >= Lout) { a1 = 0.f; a2 = 0.f; b1 = 0.f; b2 = 0.f; }      // (Lout <= To: no statistics beyond the utterance's length)
             a1 = wave_sum_to_lane63_b(a1); a2 = wave_sum_to_lane63_b(a2);
             b1 = wave_sum_to_lane63_b(b1); b2 = wave_sum_to_lane63_b(b2);
             const int n0 = n - c;
-            const int nv = (p.To - n0 < 32) ? p.To - n0 : 32;
+            const int nv = (Lout - n0 < 32) ? Lout - n0 : 32;
             if (lane == 63 && nv > 0) {
                 const float cnt = 16.0f * (float)nv, rc = 1.0f / cnt;
                 float2* gp = p.gnpart_out + ((long long)b * (Ck >> 4) + (tile0 >> 4)) * ((p.To + 31) >> 5) + (n0 >> 5);
@@ -685,6 +688,17 @@ struct Bf3Kernel {
                 }
             }
         }
+        if (p.lens) {      // ragged batch: frames at and beyond this utterance's length are written as zeros (conv_dma.hip epilogue)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (t0 + wn * TN * 32 + j * 32 + c >= Lout) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (i >= ni) break;
@@ -711,7 +725,7 @@ __global__ void __launch_bounds__(256, (Bf3Cfg<BM, BN, KT, STRIDE, UPS, BK, NST,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Bf3Kernel<BM, BN, KT, STRIDE, UPS, BK, NST, NPROD, FMT, GNF> k(p, smem);
     k.setup();
-    k.mainloop();
+    if (!k.dead_tile()) k.mainloop();      // (ragged batch: a tile wholly beyond its utterance's length only writes its zeros)
     k.epilogue();
 }
 
@@ -734,7 +748,7 @@ __global__ void __launch_bounds__(256, (Bf3PairCfg<BM, BN, BK3, BK1, NST, FMT>::
     {
         K3 k3(pp.a3, smem);
         k3.setup();
-        k3.mainloop();
+        if (!k3.dead_tile()) k3.mainloop();
 #pragma unroll
         for (int i = 0; i < K3::TM; ++i)
 #pragma unroll
@@ -742,7 +756,7 @@ __global__ void __launch_bounds__(256, (Bf3PairCfg<BM, BN, BK3, BK1, NST, FMT>::
     }
     __syncthreads();                // every wave is done reading the first phase's stages
     k1.setup_keep_acc();
-    k1.mainloop();
+    if (!k1.dead_tile()) k1.mainloop();
     k1.epilogue();
 }
 
@@ -905,7 +919,6 @@ static hipError_t split_dispatch(const DmaConvArgs& a_, int cfg, int nprod, hipS
     DmaConvArgs a = a_;
     a.ksplit = 1;
     if (a.Ci % 16 || a.C1 % 16 || a.Mp % 32 || a.B <= 0 || a.To <= 0 || a.pad < 0 || a.pad > 1 || a.voc) return hipErrorInvalidValue;
-    if (a.lens) return hipErrorInvalidValue;      // per-utterance lengths are built for the exact-fp32 kernels only
     if (a.KT != 1 && a.KT != 3) return hipErrorInvalidValue;
     int bm, bn, bk, nst;
     bf3_pick(a, cfg, bm, bn, bk, nst, FMT);

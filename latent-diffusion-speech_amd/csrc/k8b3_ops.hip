@@ -2,6 +2,7 @@
 // (+SiLU) materialised once per tensor (reference nn.GroupNorm / SiLU in resnet.py:591-641, transformer_1d.py:134,262), nearest
 // resampling.  Same structure and statistics path as k4p_ops.hip: an 8-channel block is one contiguous run of 3*(T+2) 16-byte
 // entries; a thread owns one frame of the block (three 16-byte loads -> 8 fp32 values, exact -> ... -> three 16-byte stores).
+#include "k4p.h"
 #include "k8b3.h"
 #include "kernels.h"
 
@@ -42,28 +43,28 @@ static __device__ __forceinline__ void sp_load(const char* base, int Tp, int ent
 
 // one workgroup per (b, 8-channel block)
 template <int FMT>
-__global__ void __launch_bounds__(256) to_k8b3_kernel(const float* __restrict__ in, char* __restrict__ out, int C, int T, int Ctot, int c_off) {
+__global__ void __launch_bounds__(256) to_k8b3_kernel(const float* __restrict__ in, char* __restrict__ out, int C, int T, int Ctot, int c_off, const int* __restrict__ lens) {
     constexpr int NPL = fmt_planes(FMT);
     const int q = blockIdx.x, b = blockIdx.y;
-    const int Tp = T + 2;
+    const int Tp = T + 2, Tv = ragged_len(lens, b, 0, T);      // (ragged batch: zeros from the utterance's length on)
     char* ob = out + (((long long)b * (Ctot >> 3) + (c_off >> 3) + q) * NPL) * Tp * 16;
     const float* ib = in + ((long long)b * C + q * 8) * T;
     for (int e = threadIdx.x; e < Tp; e += 256) {
         const int t = e - 1;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (t >= 0 && t < T) ? ib[(long long)j * T + t] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = (t >= 0 && t < Tv) ? ib[(long long)j * T + t] : 0.f;
         u32x4 pl[NPL];
         sp_split8<FMT>(v, pl);
 #pragma unroll
         for (int w = 0; w < NPL; ++w) *reinterpret_cast<u32x4*>(ob + ((long long)w * Tp + e) * 16) = pl[w];
     }
 }
-hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, int fmt) {
+hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, int fmt, const int* lens) {
     if ((C & 7) || (Ctot & 7) || (c_off & 7)) return hipErrorInvalidValue;
     ProfScope ps(s, "to_k8b3", 0.0, (4.0 + 2.0 * fmt_planes(fmt)) * B * (double)C * T);
-    if (fmt == FMT_F16X2) hipLaunchKernelGGL(to_k8b3_kernel<FMT_F16X2>, dim3(C / 8, B), dim3(256), 0, s, in, (char*)out, C, T, Ctot, c_off);
-    else hipLaunchKernelGGL(to_k8b3_kernel<FMT_BF16X3>, dim3(C / 8, B), dim3(256), 0, s, in, (char*)out, C, T, Ctot, c_off);
+    if (fmt == FMT_F16X2) hipLaunchKernelGGL(to_k8b3_kernel<FMT_F16X2>, dim3(C / 8, B), dim3(256), 0, s, in, (char*)out, C, T, Ctot, c_off, lens);
+    else hipLaunchKernelGGL(to_k8b3_kernel<FMT_BF16X3>, dim3(C / 8, B), dim3(256), 0, s, in, (char*)out, C, T, Ctot, c_off, lens);
     return hipGetLastError();
 }
 
@@ -167,9 +168,11 @@ template <int E, int FMT>
 __global__ void __launch_bounds__(256) gn_stream_bf3_kernel(const char* __restrict__ x1, const char* __restrict__ x2, int C1, int C2, int T, int groups,
                                                             float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ ss, int ss_stride, int ss_off, int silu,
-                                                            const float2* __restrict__ gp1, const float2* __restrict__ gp2, char* __restrict__ y) {
+                                                            const float2* __restrict__ gp1, const float2* __restrict__ gp2, char* __restrict__ y,
+                                                            const int* __restrict__ lens, int lvl) {
     constexpr int NPL = fmt_planes(FMT);
     const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int Tv = ragged_len(lens, b, lvl, T);      // ragged batch: statistics over, and output for, the utterance's own frames; zeros beyond
     const int C = C1 + C2, Tp = T + 2, nq1 = C1 >> 3, nq = C >> 3;
     const char* xb = (q < nq1) ? x1 + (((long long)b * nq1 + q) * NPL) * Tp * 16 : x2 + (((long long)b * (C2 >> 3) + (q - nq1)) * NPL) * Tp * 16;
     char* yb = y + (((long long)b * nq + q) * NPL) * Tp * 16;
@@ -206,9 +209,11 @@ __global__ void __launch_bounds__(256) gn_stream_bf3_kernel(const char* __restri
         float nb = 0.f, mb = 0.f, qb = 0.f;
         if (pi < P) {
             const int kk = (int)(((float)pi + 0.5f) * inv_nT), tb = pi - kk * nT, kb = g * cg16 + kk;
-            const float2 pr = (kb < nk1) ? gp1[((long long)b * nk1 + kb) * nT + tb] : gp2[((long long)b * (C2 >> 4) + (kb - nk1)) * nT + tb];
-            const int nv = (T - tb * 32 < 32) ? T - tb * 32 : 32;
-            nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
+            const int nv = (Tv - tb * 32 < 32) ? Tv - tb * 32 : 32;
+            if (nv > 0) {
+                const float2 pr = (kb < nk1) ? gp1[((long long)b * nk1 + kb) * nT + tb] : gp2[((long long)b * (C2 >> 4) + (kb - nk1)) * nT + tb];
+                nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
+            }
         }
         chan8(n, mean, m2, nb, mb, qb);
     }
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(256) gn_stream_bf3_kernel(const char* __restri
                 for (int j = 0; j < 8; ++j) {
                     float r = (v[j] - mu) * ga[j] + be[j];
                     if (silu) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                    v[j] = r;
+                    v[j] = (t < Tv) ? r : 0.f;
                 }
                 u32x4 o[NPL];
                 sp_split8<FMT>(v, o);
@@ -261,12 +266,13 @@ __global__ void __launch_bounds__(256) gn_stream_bf3_kernel(const char* __restri
 
 template <int FMT>
 static hipError_t gn_stream_launch(const void* x1, const void* x2, int C1, int C2, int T, int groups, float eps, const float* gamma, const float* beta,
-                                   const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, void* y, int B, hipStream_t s) {
+                                   const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, void* y, int B, hipStream_t s,
+                                   const int* lens, int lvl) {
     const int C = C1 + C2;
     ProfScope ps(s, "gn_stream_bf3", 0.0, 2.0 * fmt_planes(FMT) * 2.0 * B * (double)C * T, true);
     const dim3 grid(C / 8, B), blk(256);
     const int need = (T + 255) / 256;
-#define GN_ARGS (const char*)x1, (const char*)(x2 ? x2 : x1), C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2 ? gp2 : gp1, (char*)y
+#define GN_ARGS (const char*)x1, (const char*)(x2 ? x2 : x1), C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2 ? gp2 : gp1, (char*)y, lens, lvl
     hipEvent_t e0, e1;
     if (prof_attach_events(&e0, &e1)) {
         if (need <= 1) hipExtLaunchKernelGGL((gn_stream_bf3_kernel<1, FMT>), grid, blk, 0, s, e0, e1, 0, GN_ARGS);
@@ -278,20 +284,23 @@ static hipError_t gn_stream_launch(const void* x1, const void* x2, int C1, int C
 }
 hipError_t launch_gn_stream_bf3(const void* x1, const void* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                                 const float* beta, const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2,
-                                void* y, int B, hipStream_t s, int fmt) {
+                                void* y, int B, hipStream_t s, int fmt, const int* lens, int lvl) {
     const int C = C1 + C2;
     if ((C1 & 15) || (C2 & 15) || groups <= 0 || C % groups || (C / groups) % 16 || !gp1 || (C2 && !gp2)) return hipErrorInvalidValue;
-    return fmt == FMT_F16X2 ? gn_stream_launch<FMT_F16X2>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s)
-                            : gn_stream_launch<FMT_BF16X3>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s);
+    return fmt == FMT_F16X2 ? gn_stream_launch<FMT_F16X2>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, lens, lvl)
+                            : gn_stream_launch<FMT_BF16X3>(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, lens, lvl);
 }
 
 // nearest-neighbour resample along frames (K8B3 -> K8B3), reference F.interpolate(size=Tout); one workgroup per (b, block, plane) row
-__global__ void __launch_bounds__(256) resample_k8b3_kernel(const char* __restrict__ in, char* __restrict__ out, int Tin, int Tout) {
+__global__ void __launch_bounds__(256) resample_k8b3_kernel(const char* __restrict__ in, char* __restrict__ out, int Tin_, int Tout_, int rows_per_b,
+                                                            const int* __restrict__ lens, int lvl_in, int lvl_out) {
     const long long row = blockIdx.x;
+    const int b = (int)(row / rows_per_b);
+    const int Tin = ragged_len(lens, b, lvl_in, Tin_), Tout = ragged_len(lens, b, lvl_out, Tout_);      // ragged batch: the utterance's own lengths
     const float sc = (float)Tin / (float)Tout;
-    const char* ib = in + row * (Tin + 2) * 16;
-    char* ob = out + row * (Tout + 2) * 16;
-    for (int e = threadIdx.x; e < Tout + 2; e += 256) {
+    const char* ib = in + row * (Tin_ + 2) * 16;
+    char* ob = out + row * (Tout_ + 2) * 16;
+    for (int e = threadIdx.x; e < Tout_ + 2; e += 256) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (e >= 1 && e <= Tout) {
             int src = (int)floorf((float)(e - 1) * sc);
@@ -301,9 +310,10 @@ __global__ void __launch_bounds__(256) resample_k8b3_kernel(const char* __restri
         *reinterpret_cast<u32x4*>(ob + (long long)e * 16) = v;
     }
 }
-hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin, int Tout, hipStream_t s, int fmt) {
+hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin, int Tout, hipStream_t s, int fmt, const int* lens, int lvl_in, int lvl_out) {
     ProfScope ps(s, "resample", 0.0, 2.0 * fmt_planes(fmt) * B * (double)C * (Tin + Tout));
-    hipLaunchKernelGGL(resample_k8b3_kernel, dim3((unsigned)((long long)B * (C / 8) * fmt_planes(fmt))), dim3(256), 0, s, (const char*)in, (char*)out, Tin, Tout);
+    hipLaunchKernelGGL(resample_k8b3_kernel, dim3((unsigned)((long long)B * (C / 8) * fmt_planes(fmt))), dim3(256), 0, s, (const char*)in, (char*)out, Tin, Tout,
+                       (C / 8) * fmt_planes(fmt), lens, lvl_in, lvl_out);
     return hipGetLastError();
 }
 

@@ -140,14 +140,14 @@ bool conv_bf3_pair_applies(const DmaConvArgs& a3, const DmaConvArgs& a1);
 const char* conv_bf3_last_config();
 void conv_bf3_set_debug_rule(int r);      // tuning only (lds_debug_set_split_rule)
 // split-plane helpers (k8b3_ops.hip): plain [B][C][T] <-> K8B3 / K8H2 (channels [c_off, c_off + C) of a tensor with Ctot channels); fmt as above
-hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, int fmt = 0);
+hipError_t launch_to_k8b3(const float* in, void* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s, int fmt = 0, const int* lens = nullptr);
 hipError_t launch_from_k8b3(const void* in, float* out, int B, int C, int T, hipStream_t s, int fmt = 0);
 // GroupNorm(+scale/shift)(+SiLU) of the virtual concat [x1;x2], split planes in and out; same statistics path as launch_gn_stream
 hipError_t launch_gn_stream_bf3(const void* x1, const void* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                                 const float* beta, const float* scale_shift, int ss_stride, int ss_off, int silu, const float2* gp1,
-                                const float2* gp2, void* y, int B, hipStream_t s, int fmt = 0);
+                                const float2* gp2, void* y, int B, hipStream_t s, int fmt = 0, const int* lens = nullptr, int lvl = 0);
 hipError_t launch_gn_partials_bf3(const void* x, int C, int T, float2* gp, int B, hipStream_t s, int fmt = 0);
-hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin, int Tout, hipStream_t s, int fmt = 0);
+hipError_t launch_resample_k8b3(const void* in, void* out, int B, int C, int Tin, int Tout, hipStream_t s, int fmt = 0, const int* lens = nullptr, int lvl_in = 0, int lvl_out = 0);
 
 // ---------------------------------------------------------------------------------------------
 // K4P helpers (k4p_ops.hip)
@@ -184,7 +184,8 @@ hipError_t launch_attention_k4p(const float* qk, const float* vt, float* out, in
                                 const int* lens = nullptr, int lvl = 0);
 // the same with the output written as a K8B3 tensor (split-bf16 path: the output feeds the to_out projection)
 hipError_t launch_attention_k4p_f16math(const float* qk, const float* vt, float* out, int B, int C, int T, int heads, hipStream_t s, int tile_batch = 0);
-hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0, int tile_batch = 0);
+hipError_t launch_attention_k4p_out_bf3(const float* qk, const float* vt, void* out, int B, int C, int T, int heads, hipStream_t s, int fmt = 0, int tile_batch = 0,
+                                        const int* lens = nullptr, int lvl = 0);
 
 // ---------------------------------------------------------------------------------------------
 // Small dense layers with N = batch columns (time embedding path)

@@ -625,13 +625,15 @@ static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, cons
 }
 
 static int run_dconv_pair_bf3(const ConvW& W3, const void* h, const ConvW& W1, const void* x1, int C1, const void* x2, int C2, int T, const float* bias_pair,
-                              float2* gnpart_out, void* out, int B, hipStream_t st, int fmt) {
+                              float2* gnpart_out, void* out, int B, hipStream_t st, int fmt, int lvl = 0) {
     DmaConvArgs a3, a1;
     DOpt o3;
+    o3.lvl_in = o3.lvl_out = lvl;
     o3.pad = 1;
     int rc = fill_dconv(W3, (const float*)h, W3.Ci, nullptr, 0, T, o3, (float*)out, B, a3);
     if (rc != LDS_OK) return rc;
     DOpt o1;
+    o1.lvl_in = o1.lvl_out = lvl;
     o1.gnpart_out = gnpart_out;
     rc = fill_dconv(W1, (const float*)x1, C1, (const float*)x2, C2, T, o1, (float*)out, B, a1);
     if (rc != LDS_OK) return rc;
@@ -673,11 +675,11 @@ static int dconv_any(int mode, const ConvW& W, const float* x1, int C1, const fl
 }
 static hipError_t gn_any(int mode, const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma, const float* beta,
                          const float* ss, int ss_stride, int ss_off, int silu, const float2* gp1, const float2* gp2, float* y, int B, hipStream_t s, int lvl = 0) {
-    return mode ? launch_gn_stream_bf3(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, mode - 1)
+    return mode ? launch_gn_stream_bf3(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, mode - 1, tl_lens, lvl)
                 : launch_gn_stream(x1, x2, C1, C2, T, groups, eps, gamma, beta, ss, ss_stride, ss_off, silu, gp1, gp2, y, B, s, tl_lens, lvl);
 }
 static hipError_t to_act_any(int mode, const float* in, float* out, int B, int C, int T, int Ctot, int c_off, hipStream_t s) {
-    return mode ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s, mode - 1) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s, tl_lens);
+    return mode ? launch_to_k8b3(in, out, B, C, T, Ctot, c_off, s, mode - 1, tl_lens) : launch_to_k4p(in, out, B, C, T, Ctot, c_off, s, tl_lens);
 }
 
 // ================================================================================================
@@ -1137,7 +1139,7 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     const float* res = x1;
     if (r.has_sc) {
         // the shortcut rides in conv2's launch (second reduction into the same accumulators; skip-concat on read: two source pointers)
-        const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, bf3 - 1)
+        const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, bf3 - 1, lvl)
                            : run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, lvl);
         if (rc != 1) return rc;
         DOpt os;      // no fused variant for these shapes: two launches
@@ -1178,7 +1180,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
         oq.out_f32 = bf3 ? 1 : 0;                                          // (split-bf16 mode: q / k / v stay fp32 for the attention kernel)
         LDS_TRY(dconv_any(bf3, t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
-        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1, tl_tile_batch));
+        if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1, tl_tile_batch, tl_lens, lvl));
         else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st, tl_tile_batch, tl_lens, lvl));
         DOpt oo;
         oo.lvl_in = oo.lvl_out = lvl;
@@ -1198,10 +1200,9 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
 }
 
 // Ragged batches: per-utterance lengths (host int32 [B], 1 <= len <= T; null = none) -> the workspace's device copy, carried in a launch's
-// kernel arguments (<= 64 utterances).  Split GEMM modes have no masked kernels.
+// kernel arguments (<= 64 utterances).
 static int ragged_len_host(int n, int lvl) { for (int i = 0; i < lvl; ++i) n = (n - 1) / 2 + 1; return n; }
 static int upload_lens(const lds_unet* u, const int* lens_host, int B, int T, int* dev, hipStream_t st) {
-    if (u->gemm_mode != LDS_GEMM_F32) return fail(LDS_EINVAL, "per-utterance lengths are built for the exact-fp32 GEMM mode");
     if (B > 64) return fail(LDS_EINVAL, "per-utterance lengths: at most 64 utterances per call (got %d)", B);
     float tmp[64];
     for (int b = 0; b < B; ++b) {
@@ -1253,7 +1254,6 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     if (!A.ok) return fail(LDS_ENOMEM, "unet workspace too small: need %zu bytes, got %zu", A.used, ws_bytes);
     // ragged batch: the lengths reach the device once per call (per run when the sampler staged them with the condition)
     if (lens_host && !cond_staged) LDS_TRY(upload_lens(u, lens_host, B, T, w.lens_dev, st));
-    if (lens_host && u->gemm_mode != LDS_GEMM_F32) return fail(LDS_EINVAL, "per-utterance lengths are built for the exact-fp32 GEMM mode");
     LensScope lsc(lens_host ? w.lens_dev : nullptr);
     TileBatchScope tbs(u->latency_mode ? B : 0, w.kpart, w.kcount);
     // the counters are left at zero by every launch that uses them; a forward starts from zeroed ones whatever the workspace held before
@@ -1345,7 +1345,7 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
                 o.ups = 1;
                 LDS_TRY(dconv_any(bf3, b.up, cur, b.ch, nullptr, 0, Tl, o, dst, B, st));
             } else {
-                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st, bf3 - 1) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st, tl_lens, lvl, lvl - 1));
+                HIP_TRY(bf3 ? launch_resample_k8b3(cur, w.upt, B, b.ch, Tl, Tn, st, bf3 - 1, tl_lens, lvl, lvl - 1) : launch_resample_k4p(cur, w.upt, B, b.ch, Tl, Tn, st, tl_lens, lvl, lvl - 1));
                 LDS_TRY(dconv_any(bf3, b.up, w.upt, b.ch, nullptr, 0, Tn, o, dst, B, st));
             }
             Tl = Tn;

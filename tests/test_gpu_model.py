@@ -437,22 +437,13 @@ def test_latency_sampler_bench_size_vs_oracle(unit2mel_latency, unet_weights, mo
 
 
 # ---- ragged batches in one call (lds_unet_forward_ragged / lds_sampler_run_ragged): per-utterance lengths inside buffers of T frames ----
-@pytest.fixture(scope="module")
-def unit2mel_f32():
-    assert torch.cuda.is_available(), "GPU tests need a HIP device"
-    from diffusion.unit2mel import Unit2Mel
-    m = Unit2Mel(1280, 323, 80)
-    m.to("cuda").eval()
-    return m
-
-
 @pytest.mark.parametrize("T,lens,latency", [(77, [77, 50, 33], False), (512, [512, 300, 272, 401], False), (130, [64, 130, 7, 129, 2], False),
                                             (512, [301, 512], True), (200, [200] * 3, False)])
-def test_ragged_unet_forward_vs_alone(unit2mel_f32, unet_weights, T, lens, latency, record_margin):
+def test_ragged_unet_forward_vs_alone(unit2mel_gpu, unet_weights, T, lens, latency, record_margin):
     """every utterance of a padded batch against the same utterance evaluated alone at its own length (odd lengths at every level: the
     decoder resamples each utterance to its own skip lengths; lengths 2 and 7: levels of one frame); zeros beyond each length"""
     from lds import init_weights
-    unet = unit2mel_f32.decoder.denoise_fn
+    unet = unit2mel_gpu.decoder.denoise_fn
     unet.set_latency_mode(latency)
     try:
         B = len(lens)
@@ -477,10 +468,10 @@ def test_ragged_unet_forward_vs_alone(unit2mel_f32, unet_weights, T, lens, laten
 
 
 @pytest.mark.parametrize("method,speedup", [("dpm-solver", 250), ("unipc", 250), ("ddim", 250)])
-def test_ragged_sampler_vs_alone(unit2mel_f32, monkeypatch, method, speedup, record_margin):
+def test_ragged_sampler_vs_alone(unit2mel_gpu, monkeypatch, method, speedup, record_margin):
     """GaussianDiffusion.forward_ragged: a padded batch of three lengths through a 4-step run, every utterance against its own run alone"""
     from lds import init_weights
-    gd = unit2mel_f32.decoder
+    gd = unit2mel_gpu.decoder
     T, lens = 96, [96, 61, 40]
     B = len(lens)
     cond = init_weights.uniform("rag.s.cond", (B, T, 256), 71, -1, 1)
@@ -495,14 +486,3 @@ def test_ragged_sampler_vs_alone(unit2mel_f32, monkeypatch, method, speedup, rec
         worst = max(worst, relmax(y[b:b + 1, :n].cpu().numpy(), alone.cpu().numpy()))
         assert n == T or float(y[b, n:].abs().max()) == 0.0
     record_margin(worst, 1e-4)
-
-
-def test_ragged_rejected_in_split_modes(unit2mel_f32):
-    unet = unit2mel_f32.decoder.denoise_fn
-    unet.set_gemm_mode("split_f16")
-    try:
-        x = torch.zeros(2, 336, 64, device="cuda")
-        with pytest.raises(RuntimeError, match="exact-fp32"):
-            unet.native().forward(x[:, :80].contiguous(), x[:, 80:].contiguous(), torch.zeros(2, device="cuda"), lengths=[64, 30])
-    finally:
-        unet.set_gemm_mode("f32")
