@@ -29,6 +29,16 @@ assert u.gemm_mode() == 1
 native.check(L.lds_sampler_workspace_bytes(u.h, 3, 2050, C.byref(nb))); assert nb.value > f32
 u.set_gemm_mode("f32")
 assert L.lds_unet_set_gemm_mode(u.h, 7) == -1 and L.lds_unet_workspace_bytes(u.h, 0, 5, C.byref(nb)) == -1
+# ragged batches: the per-utterance lengths are validated before anything is launched
+native.check(L.lds_unet_workspace_bytes(u.h, 3, 77, C.byref(nb)))
+wsb = (C.c_char * nb.value)(); dummy = (C.c_float * 8)()
+for lens, msg in (((77, 0, 5), "length[1]"), ((77, 78, 5), "length[1]")):
+    rc = L.lds_unet_forward_ragged(u.h, dummy, dummy, dummy, (C.c_int32 * 3)(*lens), dummy, wsb, C.c_size_t(nb.value), 3, 77, None)
+    assert rc == -1 and msg in L.lds_last_error().decode(), (rc, L.lds_last_error())
+assert L.lds_unet_set_latency_mode(u.h, 2) == -1 and L.lds_unet_set_latency_mode(u.h, 1) == 0 and L.lds_unet_get_latency_mode(u.h) == 1
+native.check(L.lds_unet_workspace_bytes(u.h, 1, 512, C.byref(nb))); lat = nb.value
+assert L.lds_unet_set_latency_mode(u.h, 0) == 0
+native.check(L.lds_unet_workspace_bytes(u.h, 1, 512, C.byref(nb))); assert lat - nb.value >= (16 << 20)      # the cluster split-K scratch
 bad = dict(cfg, block_out_channels=(256, 100, 512, 512))
 try:
     native.UNet(bad, {{}}); raise SystemExit("accepted an unsupported width")
