@@ -33,6 +33,9 @@ def parse_args(argv=None):
     ap.add_argument("-me", "--method", default="dpm-solver")
     ap.add_argument("--scale_factor", type=float, default=None,
                     help="nearest-resample the unit frames by this factor first (22_infer_tts.py:108-110, units_forced_alignment)")
+    ap.add_argument("--latency_mode", action="store_true",
+                    help="one sentence per call: tile shapes / reduction splits from the actual batch (include/lds.h lds_unet_set_latency_mode)")
+    ap.add_argument("--gemm_mode", default="f32", choices=["f32", "split_bf16", "split_f16"], help="the UNet's GEMMs (include/lds.h lds_unet_set_gemm_mode)")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--synthetic_tokens", type=int, default=256)
     return ap.parse_args(argv)
@@ -282,6 +285,8 @@ def main(argv=None):
         tokens = torch.from_numpy(np.load(a.tokens).astype(np.int64)).to(dev) if a.tokens else None
         if a.language_model:
             lm = load_lm(a.language_model, dev)
+    svc.model.decoder.denoise_fn.set_gemm_mode(a.gemm_mode)
+    svc.model.decoder.denoise_fn.set_latency_mode(a.latency_mode)
     if a.phones:
         if lm is None:
             raise SystemExit("--phones needs --language_model (or --synthetic)")
