@@ -121,6 +121,19 @@ def text2semantic_rows(lm, phones, tones, spk_id=1, max_length=1024, phone_lengt
     return rows
 
 
+_STREAM_POOLS = {}
+
+
+def _stream_pool(dev, n):
+    """n side streams per device, created once: every (handle, stream) pair owns a workspace (lds/native.py Workspace), so the streams
+    are reused across calls instead of drawn anew"""
+    key = str(torch.device(dev))
+    pool = _STREAM_POOLS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(dev))
+    return pool[:n]
+
+
 def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None, streams=1, max_batch=16):
     """Utterances of different lengths with the SAMPLER run as one padded batch per `max_batch` rows and per-utterance lengths inside the
     kernels (Unit2Mel.forward_ragged: every utterance as if it ran alone -- statistics, attention and resampling stop at its own length;
@@ -170,7 +183,7 @@ def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, me
         return out
     dev = codebook.device
     cur = torch.cuda.current_stream(dev)
-    pool = [torch.cuda.Stream(dev) for _ in range(min(streams, len(buckets)))]
+    pool = _stream_pool(dev, min(streams, len(buckets)))
     for k, s_ in enumerate(pool):
         s_.wait_stream(cur)
         with torch.cuda.stream(s_):
@@ -225,7 +238,7 @@ def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="d
         return out
     dev = codebook.device
     cur = torch.cuda.current_stream(dev)
-    pool = [torch.cuda.Stream(dev) for _ in range(min(streams, len(buckets)))]
+    pool = _stream_pool(dev, min(streams, len(buckets)))
     for s_ in pool:
         s_.wait_stream(cur)      # the inputs were produced on the caller's stream
 
