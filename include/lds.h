@@ -152,6 +152,12 @@ int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out)
 /* z dev [B,C,T] -> wav dev [B,1,T*prod(upsample_rates)] */
 int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes,
                         int B, int T, void* stream);
+/* Ragged batch (see lds_sampler_run_ragged): lengths host int32 [B] (B <= 64) = the utterances' own frame counts inside z [B,C,T].  Every
+ * stage of the generator writes zeros beyond an utterance's (up-sampled) length -- the zero padding its convolutions see when it runs
+ * alone -- and z itself is read as zeros there; samples [0, lengths[b] * prod(rates)) of wav[b] equal the utterance decoded alone within the
+ * stated tolerance, the samples beyond are zeros. */
+int lds_vocoder_forward_ragged(lds_vocoder* v, const float* z, const int32_t* lengths, float* wav, void* ws, size_t ws_bytes,
+                               int B, int T, void* stream);
 
 /* ---- text2semantic: RoFormer encoder prefill + cached autoregressive decode (reference text2semantic/roformer/roformer.py:59-255
  *      over HF transformers RoFormerModel / RoFormerForCausalLM + GenerationMixin; called from 22_infer_tts.py:76-98) ------------- */

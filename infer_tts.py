@@ -134,14 +134,17 @@ def _stream_pool(dev, n):
     return pool[:n]
 
 
-def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None, streams=1, max_batch=16):
+def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, method="dpm-solver", noise_fn=None, streams=1, max_batch=16,
+                             ragged_vocoder=True):
     """Utterances of different lengths with the SAMPLER run as one padded batch per `max_batch` rows and per-utterance lengths inside the
     kernels (Unit2Mel.forward_ragged: every utterance as if it ran alone -- statistics, attention and resampling stop at its own length;
-    within the parity tolerances of the stand-alone run, not bit for bit), then the vocoder per length bucket (on `streams` HIP streams).
+    within the parity tolerances of the stand-alone run, not bit for bit), then the vocoder on the same padded batch (ragged_vocoder, the
+    default: lds_vocoder_forward_ragged) or per length bucket on `streams` HIP streams.
     Rows are sorted by length so that a padded batch wastes few frames.  Returns [(mel [T,M], wav [T*hop])] in the order of `token_rows`."""
     from lds import native
     order = sorted((i for i, r in enumerate(token_rows) if r.numel() > 0), key=lambda i: -int(token_rows[i].numel()))
     mels = [None] * len(token_rows)
+    wavs = [None] * len(token_rows)
     for c0 in range(0, len(order), max_batch):
         idx = order[c0:c0 + max_batch]
         lens = [int(token_rows[i].numel()) for i in idx]
@@ -160,9 +163,16 @@ def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, me
             mel = svc.call_ragged(units, lens, spk_id=spk_id, infer_speedup=speedup, method=method)
         finally:
             torch.randn = real
+        if ragged_vocoder:      # ... and the vocoder on the same padded batch, every stage masked at the utterance's up-sampled length
+            wav = svc.vocoder.infer_ragged(mel, lens)
+            hop = wav.shape[-1] // T
+            for j, i in enumerate(idx):
+                wavs[i] = wav[j, 0, :lens[j] * hop].contiguous()
         for j, i in enumerate(idx):
             mels[i] = mel[j, :lens[j]].contiguous()
-    # the vocoder has no normalisation across frames but its activations leak across a padded tail: per length bucket, as before
+    if ragged_vocoder:
+        return [(mels[i], wavs[i]) if token_rows[i].numel() else (torch.empty(0, codebook.shape[1]), torch.empty(0)) for i in range(len(token_rows))]
+    # ragged_vocoder = False: the vocoder per length bucket (bit-identical with each mel decoded alone)
     out = [None] * len(token_rows)
     by_len = {}
     for i, r in enumerate(token_rows):

@@ -176,6 +176,8 @@ struct DmaKernel {
         for (int j = 0; j < TN; ++j) bcol[j] = wn * TN * 32 + j * 32 + c;
     }
     __device__ __forceinline__ bool dead_tile() const { return !VOC && p.lens && t0 >= Lout; }
+    // the vocoder's lengths multiply per stage: given outright (kernels.h DmaConvArgs::vlen), fetched where they are used (the epilogue)
+    __device__ __forceinline__ int voc_len() const { return p.vlen[b]; }
     __device__ __forceinline__ void setup() {
         setup_keep_acc();
 #pragma unroll
@@ -491,6 +493,9 @@ struct DmaKernel {
             if constexpr (VOC) {
                 if (p.out_div != 1.0f) v = v / p.out_div;
                 if (p.act_slope != 0.f) v = (v >= 0.f) ? v : v * p.act_slope;
+                if constexpr (BN < 256) {      // (ragged batch: zeros beyond the utterance's length; the launcher keeps ragged calls off the 256-wide tile, which has no register to spare)
+                    if (p.vlen && n >= voc_len()) v = 0.f;
+                }
             }
             if (c0 + rl < Cn) ob[rl * p.To] = v;
         }
@@ -565,13 +570,14 @@ struct DmaKernel {
     __device__ __forceinline__ void store_phases(int tile0, int i, int j, int n) {
         const int lg = p.ph_log2, Tpo = p.ph_Tout + 2 * p.opad;
         const long long ob = (long long)b * p.ph_Cout * Tpo;
+        const int Lv = p.vlen ? voc_len() : 0x7fffffff;      // ragged batch: zeros beyond the utterance's output length
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int co = m >> lg, f = (n << lg) + (m & ((1 << lg) - 1)) - p.ph_tpad;
             const bool ok = n < p.To && f >= 0 && f < p.ph_Tout && co < p.ph_Cout;
             const long long off = ob + (long long)(((co >> 3) * 2 + (co & 1)) * Tpo + f + p.opad) * 4 + ((co & 7) >> 1);
-            const float v = acc[0][i][j][r];
+            const float v = (f < Lv) ? acc[0][i][j][r] : 0.f;
             if (ok) {
                 p.out[off] = v;
                 if (p.out_act) p.out_act[off] = (v >= 0.f) ? v : v * p.act_slope;
@@ -590,6 +596,12 @@ struct DmaKernel {
         float* ob = p.out + o0;
         if (ok) {
             if constexpr (VOC) {
+            if constexpr (BN < 256) {
+                if (p.vlen && n >= voc_len()) {      // ragged batch: this stage's frames beyond the utterance's length are written as zeros
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] = 0.f;
+                }
+            }
             if (p.out_div != 1.0f) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][i][j][r] = acc[0][i][j][r] / p.out_div;
@@ -791,7 +803,7 @@ struct DmaKernel {
             for (int j = 0; j < TN; ++j) {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
                 const int tile0 = tile_ch(i, geglu);
-                if constexpr (VOC) {
+                if constexpr (VOC && KT == 2) {      // (the polyphase upsamplers are the 2-tap instantiations)
                     if (p.ph_Tout) { store_phases(tile0, i, j, n); continue; }
                 }
                 if (p.out_plain) store_plain(p.out, p.Cout, tile0, i, j, n);
@@ -1036,7 +1048,7 @@ hipError_t launch_conv_dma(const DmaConvArgs& a_, int cfg, hipStream_t s) {
 #define VCASE(KT_, D_) if (a.KT == KT_ && a.dil == D_) return launch_dma_cfg<64, 128, KT_, 1, false, 16, 2, D_, true>(a, s)
         // one M-block (64 output channels) and 11 taps: a 256-frame tile amortises the 45 KB weight tile over twice the columns
         // (measured 104 -> 114 TFLOP/s with the residual epilogue; k 3 / k 7 lose 7 % on the wide tile)
-        if (a.Mp == 64 && a.KT == 11 && a.To >= 1024) {
+        if (a.Mp == 64 && a.KT == 11 && a.To >= 1024 && !a.vlen) {
 #define WCASE(D_) if (a.dil == D_) return launch_dma_cfg<64, 256, 11, 1, false, 16, 2, D_, true>(a, s)
             WCASE(1); WCASE(3); WCASE(5);
 #undef WCASE

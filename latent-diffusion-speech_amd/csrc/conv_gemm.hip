@@ -77,6 +77,7 @@ struct ConvKernel {
     float* smem;
     bool producer;
     int tid, c, h, wm, wn, b, m0, t0;
+    int in_valid, out_valid;      // ragged batch: this batch element's valid input / output frames
     int s_al, off, xw4, xwp, stage;
     bool vec_ok;
     int xrr, xc0, arow;
@@ -103,6 +104,8 @@ struct ConvKernel {
         const int mb = blockIdx.x % nMb;          // M fastest: blocks that share an activation tile are neighbours
         const int nb = blockIdx.x / nMb;
         b = blockIdx.y;
+        in_valid = p.vlen_in ? (p.vlen_in[b] < p.Tsrc ? p.vlen_in[b] : p.Tsrc) : p.Tsrc;      // ragged batch (kernels.h ConvArgs::vlen_in / vlen)
+        out_valid = p.vlen ? p.vlen[b] : 0x7fffffff;
         m0 = mb * BM; t0 = nb * BN;
         int width;
         if (UPS) {
@@ -198,7 +201,7 @@ struct ConvKernel {
             const int c4 = xc0 + I * TPR;
             if (c4 < xw4) {
                 const int s = s_al + c4 * 4 + E;
-                const bool inb = (s >= 0 && s < p.Tsrc);
+                const bool inb = (s >= 0 && s < in_valid);
                 f32x4 v;
                 if constexpr (MODE == M_PLAIN) {
 #pragma unroll
@@ -360,12 +363,13 @@ struct ConvKernel {
     // kept OUT of the per-element loops: a branch inside them splits the loop body into basic blocks and the loads of
     // different elements can then no longer be issued together.
     template <bool PH>
-    __device__ __forceinline__ bool elem(int i, int r, int n, int& co, long long& oi) const {
+    __device__ __forceinline__ bool elem(int i, int r, int n, int& co, long long& oi, bool* live = nullptr) const {
         const int orow = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         co = orow;
         int to = n;
         if constexpr (PH) { co = orow / p.phases; to = n * p.phases + (orow - co * p.phases) - p.tpad; }
         oi = ((long long)b * p.Cout + co) * p.Tout + to;
+        if (live) *live = to < out_valid;      // (ragged batch: output frames beyond the utterance's length are stored as zeros)
         return co < p.Cout && n < p.To && to >= 0 && to < p.Tout;
     }
 
@@ -416,8 +420,8 @@ struct ConvKernel {
                 const int n = t0 + wn * TN * 32 + j * 32 + c;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int co; long long oi;
-                    if (elem<PH>(i, r, n, co, oi)) p.out[oi] = acc[0][i][j][r];
+                    int co; long long oi; bool live;
+                    if (elem<PH>(i, r, n, co, oi, &live)) p.out[oi] = live ? acc[0][i][j][r] : 0.f;
                 }
             }
     }

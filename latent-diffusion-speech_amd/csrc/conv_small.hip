@@ -77,11 +77,12 @@ __global__ void __launch_bounds__(256) conv_small_kernel(const ConvArgs p, int n
             const int s = s_al + 4 * c4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < C * W4) {
-                if (vec && s >= 0 && s + 3 < T) {
+                const int Tv = p.vlen_in ? (p.vlen_in[b] < T ? p.vlen_in[b] : T) : T;      // (ragged batch: the input reads as zeros beyond its length)
+                if (vec && s >= 0 && s + 3 < Tv) {
                     v = *reinterpret_cast<const f32x4*>(xb + (long long)ci * T + s);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < T) ? xb[(long long)ci * T + s + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = (s + e >= 0 && s + e < Tv) ? xb[(long long)ci * T + s + e] : 0.f;
                 }
             }
             xr[i] = v;
@@ -138,13 +139,14 @@ __global__ void __launch_bounds__(256) conv_small_kernel(const ConvArgs p, int n
 #pragma unroll
                         for (int r = 0; r < 4; ++r) av[r] = p.out[o + (long long)r * p.To];
                     }
+                    const bool live = !p.vlen || t < p.vlen[b];      // (ragged batch: zeros beyond the utterance's length)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float y = d[r] + bias4[r];
                         y += rv[r];
                         y += av[r];
                         if (p.out_div != 1.0f) y = y / p.out_div;
-                        p.out[o + (long long)r * p.To] = y;
+                        p.out[o + (long long)r * p.To] = live ? y : 0.f;
                     }
                 }
             }
@@ -219,6 +221,10 @@ __global__ void __launch_bounds__(256) conv_mono_kernel(const ConvArgs p) {
     if (p.epi == EPI_TANH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]);
+    }
+    if (p.vlen) {      // ragged batch: zeros beyond the utterance's length
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (t + e < p.vlen[b]) ? o[e] : 0.f;
     }
     float* ob = p.out + (long long)b * T + t;
     if ((T & 3) == 0) *reinterpret_cast<f32x4*>(ob) = f32x4{o[0], o[1], o[2], o[3]};

@@ -45,8 +45,9 @@ hipError_t launch_to_k4p(const float* in, float* out, int B, int C, int T, int C
 // frames), the raw tensor (residual operand) and its LeakyReLU (what the convolutions read: reference models.py:186-192 applies
 // F.leaky_relu before every conv, here once per tensor).  One workgroup per (8-channel block, 1024-frame slab, batch element).
 __global__ void __launch_bounds__(256) to_k4p_act_kernel(const float* __restrict__ in, float* __restrict__ raw, float* __restrict__ act,
-                                                         float slope, int C, int T, int pad) {
+                                                         float slope, int C, int T, int pad, const int* __restrict__ vlen) {
     const int q = blockIdx.x, t0 = blockIdx.y * 1024, b = blockIdx.z;
+    const int Tv = vlen ? vlen[b] : T;      // (ragged batch: zeros from the utterance's length on)
     const int Tp = T + 2 * pad;
     const long long ro = (((long long)b * (C >> 3) + q) * 2) * Tp * 4;
     const float* ib = in + ((long long)b * C + q * 8) * T;
@@ -55,16 +56,16 @@ __global__ void __launch_bounds__(256) to_k4p_act_kernel(const float* __restrict
         if (t >= T) continue;
         f32x4 v, a;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = ib[(long long)(2 * j + hh) * T + t]; a[j] = (v[j] >= 0.f) ? v[j] : v[j] * slope; }
+        for (int j = 0; j < 4; ++j) { v[j] = (t < Tv) ? ib[(long long)(2 * j + hh) * T + t] : 0.f; a[j] = (v[j] >= 0.f) ? v[j] : v[j] * slope; }
         const long long o = ro + ((long long)hh * Tp + t + pad) * 4;
         if (raw) *reinterpret_cast<f32x4*>(raw + o) = v;
         if (act) *reinterpret_cast<f32x4*>(act + o) = a;
     }
 }
-hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s) {
+hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s, const int* vlen) {
     if ((C & 7) || pad < 1) return hipErrorInvalidValue;
     ProfScope ps(s, "to_k4p_act", 0.0, 4.0 * B * (double)C * T * (1.0 + (raw ? 1.0 : 0.0) + (act ? 1.0 : 0.0)));
-    hipLaunchKernelGGL(to_k4p_act_kernel, dim3(C / 8, (T + 1023) / 1024, B), dim3(256), 0, s, in, raw, act, slope, C, T, pad);
+    hipLaunchKernelGGL(to_k4p_act_kernel, dim3(C / 8, (T + 1023) / 1024, B), dim3(256), 0, s, in, raw, act, slope, C, T, pad, vlen);
     return hipGetLastError();
 }
 

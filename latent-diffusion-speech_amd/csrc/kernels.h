@@ -41,6 +41,9 @@ struct ConvArgs {
     // transposed-conv scatter: row m = co*phases + phi -> out[b][co][n*phases + phi - tpad] (phases=1: plain)
     int phases, tpad, Tout;  // Tout = row length of out
     int B;
+    // Ragged batches (vocoder): valid frames per batch element of the OUTPUT tensor (device int32 [B]; output frames at and beyond are
+    // written as zeros) and of the INPUT (frames at and beyond read as zeros); null = the buffers' lengths
+    const int* vlen; const int* vlen_in;
 };
 
 // tile: 0 = auto, else BM*1000+BN in {128128, 64064, 128064, 64128, 32128}
@@ -110,6 +113,9 @@ struct DmaConvArgs {
     // Ragged batches (k4p.h ragged_len): per-utterance lengths at the UNet's input resolution and the levels of this launch's input and
     // output tensors; output frames at and beyond an utterance's length are written as zeros.  nullptr: no masking.
     const int* lens; int lvl_in, lvl_out;
+    // ... and of the vocoder's stages, whose lengths multiply instead of halving: valid OUTPUT frames per batch element (device int32 [B];
+    // of the scattered tensor in polyphase mode), written as zeros beyond; null = none
+    const int* vlen;
     // Cluster split-K (latency mode only; conv_dma.hip cluster_join): ksplit = S > 1 workgroups share an output tile, each reducing 1/S
     // of the K-steps; kpart = scratch for the partial tiles (tiles x 4 waves x S x 1024 floats), kcount = one zeroed counter per
     // (tile, wave), left zeroed.  The launchers choose S (conv_dma_cluster_split) when tile_batch > 0 and kpart / kcount are given.
@@ -172,7 +178,7 @@ hipError_t launch_gn_stream(const float* x1, const float* x2, int C1, int C2, in
 hipError_t launch_gn_partials(const float* x, int C, int T, float2* gp, int B, hipStream_t s);
 // nearest-neighbour resample along frames (K4P -> K4P), reference F.interpolate(size=Tout)
 // plain [B][C][T] -> K4P with `pad` zero frames per side: raw copy and (slope != 0) LeakyReLU copy (either output may be null)
-hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s);
+hipError_t launch_to_k4p_act(const float* in, float* raw, float* act, float slope, int B, int C, int T, int pad, hipStream_t s, const int* vlen = nullptr);
 // zero the `pad` frames on both sides of every row of a K4P tensor (tensors whose writers only store real frames)
 hipError_t launch_k4p_zero_pads(float* x, int B, int C, int T, int pad, hipStream_t s);
 // lens: per-utterance lengths (ragged_len) at levels lvl_in / lvl_out of the two tensors

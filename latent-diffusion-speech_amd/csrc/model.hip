@@ -414,6 +414,7 @@ struct ConvOpt {
     int epi = EPI_NONE; int accum = 0; float out_div = 1.f;
     int phases = 1, tpad = 0; int To = -1; int Tout = -1; int tile = 0;
     int Cout = -1;
+    const int* vlen = nullptr; const int* vlen_in = nullptr;      // ragged batches: valid output / input frames per batch element (kernels.h ConvArgs)
 };
 
 static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, int B, hipStream_t st) {
@@ -434,6 +435,7 @@ static int run_conv(const ConvW& W, const Src& s, const ConvOpt& o, float* out, 
     a.phases = o.phases; a.tpad = o.tpad;
     a.Cout = o.Cout > 0 ? o.Cout : W.Co / o.phases;
     a.B = B;
+    a.vlen = o.vlen; a.vlen_in = o.vlen_in;
     const double real_rows = (o.phases > 1) ? (double)W.Co : (double)(a.Cout);
     const double flops = 2.0 * B * (double)a.To * real_rows * (double)W.Ci * (double)W.K;
     const double bytes = 4.0 * ((double)B * W.Ci * s.Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.Tout * (o.res ? 2.0 : 1.0));
@@ -476,6 +478,7 @@ struct DOpt {
     const float2* gnf_part = nullptr; int gnf_groups = 0; float gnf_eps = 1e-5f; const float* gnf_cg = nullptr; const float* gnf_c2 = nullptr;   // GroupNorm fold
     int cfg = 0;
     int lvl_in = 0, lvl_out = 0;      // ragged batches: UNet levels of the input / output tensors (k4p.h ragged_len)
+    const int* vlen = nullptr;        // ... vocoder: valid output frames per batch element, given outright
     int out_f32 = 0;      // split-bf16 path: the K4P-range output channels stay fp32 K4P (q / k for the attention kernel)
 };
 // Batch size the launchers judge their tile / split choices at while a UNet call of this thread is running: 0 = the nominal batch (the
@@ -506,6 +509,7 @@ static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, 
     memset(&a, 0, sizeof(a));
     a.tile_batch = tl_tile_batch;
     a.lens = tl_lens; a.lvl_in = o.lvl_in; a.lvl_out = o.lvl_out;
+    a.vlen = o.vlen;
     a.kpart = tl_kpart; a.kcount = tl_kcount; a.kpart_cap = kClusterPartFloats; a.kcount_cap = kClusterCounters;
     if (C1 + C2 != W.Ci) return fail(LDS_EINVAL, "dconv: input channels %d+%d != %d", C1, C2, W.Ci);
     a.x1 = x1; a.x2 = x2 ? x2 : x1; a.C1 = C1; a.C2 = C2; a.Tsrc = Tsrc;
@@ -1696,7 +1700,7 @@ extern "C" void lds_vocoder_destroy(lds_vocoder* v) { delete v; }
 // tensor by the producer's epilogue, and the MRF's running sum is accumulated in K4P.  Narrower stages (the 32 / 16-channel
 // tail) and their upsamplers stay on the register-staged conv_gemm / conv_small over plain tensors.
 constexpr int kVocPad = 32;
-struct VocWs { float *x, *xs, *ta, *ra, *rb; float *kx_raw, *kx_act, *kt_act, *ka_raw, *ka_act, *kb_raw, *kb_act, *ks, *kin; };
+struct VocWs { float *x, *xs, *ta, *ra, *rb; float *kx_raw, *kx_act, *kt_act, *ka_raw, *ka_act, *kb_raw, *kb_act, *ks, *kin; int* vlens; };
 static bool voc_dma_stage(const lds_vocoder* v, int ch) {
     if (ch % 64) return false;
     for (const VocRes& rb : v->rbs)
@@ -1724,6 +1728,7 @@ static void plan_voc(const lds_vocoder* v, Arena& A, int B, int T, VocWs& w) {
     w.x = A.f(B * mx); w.xs = A.f(B * mx); w.ta = A.f(B * mx); w.ra = A.f(B * mx); w.rb = A.f(B * mx);
     float** kb[9] = {&w.kx_raw, &w.kx_act, &w.kt_act, &w.ka_raw, &w.ka_act, &w.kb_raw, &w.kb_act, &w.ks, &w.kin};
     for (float** pp : kb) *pp = mk ? A.f(B * mk + 4096) : nullptr;
+    w.vlens = (int*)A.f(9 * 64);      // ragged batches: per-stage valid lengths of <= 64 utterances
 }
 extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, size_t* out) {
     if (!v || !out || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
@@ -1737,10 +1742,10 @@ extern "C" int lds_vocoder_workspace_bytes(const lds_vocoder* v, int B, int T, s
 // MRF of one stage on the K4P / LDS-DMA path (reference models.py:161-222,250-259): x plain [B][ch][Tl] (null: the upsampler has
 // already written kx_raw / kx_act) -> mean_j resblock_j(x), to xs plain, or (xs null) as LeakyReLU(0.1)(.) to the K4P tensor kin,
 // the next upsampler's input
-static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const float* x, float* xs, int ch, int Tl, int B, hipStream_t st) {
+static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const float* x, float* xs, int ch, int Tl, int B, hipStream_t st, const int* vlen = nullptr) {
     const lds_vocoder_cfg& c = v->cfg;
     const int P = kVocPad;
-    if (x) HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kx_act, 0.1f, B, ch, Tl, P, st));
+    if (x) HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kx_act, 0.1f, B, ch, Tl, P, st, vlen));
     float* acts[4] = {w.kx_act, w.kt_act, w.ka_act, w.kb_act};
     for (float* a : acts) HIP_TRY(launch_k4p_zero_pads(a, B, ch, Tl, P, st));      // the epilogues below store real frames only
     if (!xs) HIP_TRY(launch_k4p_zero_pads(w.kin, B, ch, Tl, P, st));
@@ -1756,11 +1761,11 @@ static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const fl
             const int d = rb.dil[m];
             const float* in2 = cur_act;
             DOpt o2;                                   // the convolution that closes the residual step: x = conv(...) + x
-            o2.voc = 1; o2.xpad = P; o2.opad = P; o2.res = cur_raw;
+            o2.voc = 1; o2.xpad = P; o2.opad = P; o2.res = cur_raw; o2.vlen = vlen;
             const ConvW* W2 = &rb.c1[m];
             if (c.resblock == 1) {
                 DOpt o1;                               // xt = c1(lrelu(x)), stored as lrelu(xt)
-                o1.voc = 1; o1.xpad = P; o1.opad = P; o1.dil = d; o1.pad = (rb.k * d - d) / 2; o1.act_slope = 0.1f;
+                o1.voc = 1; o1.xpad = P; o1.opad = P; o1.dil = d; o1.pad = (rb.k * d - d) / 2; o1.act_slope = 0.1f; o1.vlen = vlen;
                 LDS_TRY(run_dconv(rb.c1[m], cur_act, ch, nullptr, 0, Tl, o1, w.kt_act, B, st));
                 in2 = w.kt_act; W2 = &rb.c2[m];
                 o2.pad = (rb.k - 1) / 2;
@@ -1784,7 +1789,15 @@ static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const fl
     return LDS_OK;
 }
 
+static int vocoder_forward_impl(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream, const int* lens_host);
 extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream) {
+    return vocoder_forward_impl(v, z, wav, ws, ws_bytes, B, T, stream, nullptr);
+}
+extern "C" int lds_vocoder_forward_ragged(lds_vocoder* v, const float* z, const int32_t* lengths, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream) {
+    if (!lengths) return fail(LDS_EINVAL, "bad argument");
+    return vocoder_forward_impl(v, z, wav, ws, ws_bytes, B, T, stream, lengths);
+}
+static int vocoder_forward_impl(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream, const int* lens_host) {
     if (!v || !z || !wav || !ws || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     ProfChain chain;
@@ -1793,11 +1806,32 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
     plan_voc(v, A, B, T, w);
     if (!A.ok) return fail(LDS_ENOMEM, "vocoder workspace too small: need %zu", A.used);
     const lds_vocoder_cfg& c = v->cfg;
+    // Ragged batch: stage s of utterance b has vl[s][b] valid frames (the transposed convolutions' own length formula applied to the
+    // utterance's length); every stage writes zeros beyond them, which is the zero padding the utterance's convolutions see when it runs
+    // alone.  The lists travel in kernel arguments (<= 64 utterances).
+    std::vector<const int*> vl(c.n_ups + 1, nullptr);
+    if (lens_host) {
+        if (B > 64) return fail(LDS_EINVAL, "per-utterance lengths: at most 64 utterances per call (got %d)", B);
+        std::vector<int> cur(lens_host, lens_host + B);
+        for (int i = 0; i <= c.n_ups; ++i) {
+            float tmp[64];
+            for (int b = 0; b < B; ++b) {
+                if (i == 0 && (cur[b] < 1 || cur[b] > T)) return fail(LDS_EINVAL, "length[%d] = %d outside 1 .. %d", b, cur[b], T);
+                memcpy(&tmp[b], &cur[b], sizeof(int));
+            }
+            HIP_TRY(launch_set_list((float*)(w.vlens + 64 * i), tmp, B, st));
+            vl[i] = w.vlens + 64 * i;
+            if (i < c.n_ups) {
+                const int s_ = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+                for (int b = 0; b < B; ++b) cur[b] = (cur[b] - 1) * s_ - 2 * ((k - s_ + 1) / 2) + k;
+            }
+        }
+    }
     // reference models.py:248-262
     {
         Src s{z, c.inter_channels, nullptr, 0, T};
         ConvOpt o;
-        o.pad = 3;
+        o.pad = 3; o.vlen = vl[0]; o.vlen_in = vl[0];
         LDS_TRY(run_conv(v->pre, s, o, w.x, B, st));
     }
     int ch = c.upsample_initial_channel, Tl = T;
@@ -1811,17 +1845,17 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
         if (voc_dma_ups(v, i)) {
             // x = ups[i](leaky_relu(x, 0.1)) on conv_dma: K4P in (kin), the stage's kx_raw / kx_act out
             if (!k4p_in) {
-                HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kin, 0.1f, B, ch, Tl, kVocPad, st));      // (kx_raw: scratch for the unused raw copy)
+                HIP_TRY(launch_to_k4p_act(x, w.kx_raw, w.kin, 0.1f, B, ch, Tl, kVocPad, st, vl[i]));      // (kx_raw: scratch for the unused raw copy)
                 HIP_TRY(launch_k4p_zero_pads(w.kin, B, ch, Tl, kVocPad, st));
             }
             int lg = 0;
             while ((1 << lg) < s_) ++lg;
             DOpt o;
             o.voc = 1; o.xpad = kVocPad; o.opad = kVocPad; o.pad = 1; o.act_slope = 0.1f; o.out_act = w.kx_act;
-            o.ph_log2 = lg; o.ph_tpad = (k - s_ + 1) / 2; o.ph_Tout = Tn;
+            o.ph_log2 = lg; o.ph_tpad = (k - s_ + 1) / 2; o.ph_Tout = Tn; o.vlen = vl[i + 1];
             LDS_TRY(run_dconv(v->ups[i], w.kin, ch, nullptr, 0, Tl, o, w.kx_raw, B, st));
             ch = cout; Tl = Tn;
-            LDS_TRY(voc_mrf_dma(v, w, i, nullptr, k4p_next ? nullptr : xs, ch, Tl, B, st));
+            LDS_TRY(voc_mrf_dma(v, w, i, nullptr, k4p_next ? nullptr : xs, ch, Tl, B, st, vl[i + 1]));
             if (!k4p_next) { float* t = x; x = xs; xs = t; }
             k4p_in = k4p_next;
             continue;
@@ -1831,13 +1865,13 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
             Src s{x, ch, nullptr, 0, Tl};
             ConvOpt o;
             o.pad = v->ups[i].K - 1; o.act_in = ACT_LRELU; o.slope = 0.1f;
-            o.phases = s_; o.tpad = (k - s_ + 1) / 2; o.To = Tl + 1; o.Tout = Tn; o.Cout = cout;
+            o.phases = s_; o.tpad = (k - s_ + 1) / 2; o.To = Tl + 1; o.Tout = Tn; o.Cout = cout; o.vlen = vl[i + 1]; o.vlen_in = vl[i];
             LDS_TRY(run_conv(v->ups[i], s, o, xs, B, st));
         }
         { float* t = x; x = xs; xs = t; }
         ch = cout; Tl = Tn;
         if (voc_dma_stage(v, ch)) {
-            LDS_TRY(voc_mrf_dma(v, w, i, x, xs, ch, Tl, B, st));
+            LDS_TRY(voc_mrf_dma(v, w, i, x, xs, ch, Tl, B, st, vl[i + 1]));
             { float* t = x; x = xs; xs = t; }
             continue;
         }
@@ -1851,9 +1885,9 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
                 const int d = rb.dil[m];
                 Src s1{cur, ch, nullptr, 0, Tl};
                 ConvOpt o1;
-                o1.dil = d; o1.pad = (rb.k * d - d) / 2; o1.act_in = ACT_LRELU; o1.slope = 0.1f;
+                o1.dil = d; o1.pad = (rb.k * d - d) / 2; o1.act_in = ACT_LRELU; o1.slope = 0.1f; o1.vlen = vl[i + 1];
                 ConvOpt o2;
-                o2.res = cur;
+                o2.res = cur; o2.vlen = vl[i + 1];
                 if (last) { o2.accum = j > 0; o2.out_div = (j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f; }
                 float* dst = last ? xs : pp[m & 1];
                 if (c.resblock == 1) {
@@ -1872,7 +1906,7 @@ extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, v
     }
     Src s{x, ch, nullptr, 0, Tl};
     ConvOpt o;
-    o.pad = 3; o.act_in = ACT_LRELU; o.slope = 0.01f; o.epi = EPI_TANH;
+    o.pad = 3; o.act_in = ACT_LRELU; o.slope = 0.01f; o.epi = EPI_TANH; o.vlen = vl[c.n_ups];
     return run_conv(v->post, s, o, wav, B, st);
 }
 

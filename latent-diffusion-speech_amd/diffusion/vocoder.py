@@ -26,3 +26,7 @@ class Vocoder:
 
     def infer(self, mel):
         return self.vocoder(mel)
+
+    def infer_ragged(self, mel, lengths):
+        """Extension (not in the reference): a padded ragged batch of mels [B,T,M] + per-utterance frame counts -> wav [B,1,T*hop]"""
+        return self.vocoder.forward_ragged(mel, lengths)

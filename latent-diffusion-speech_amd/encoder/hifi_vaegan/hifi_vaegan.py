@@ -40,7 +40,13 @@ class Hifi_VAEGAN(torch.nn.Module):
         raise NotImplementedError("the VAE encoder is preprocessing, outside the sampler hot path")
 
     @torch.no_grad()
-    def forward(self, z):
+    def forward_ragged(self, z, lengths):
+        """Extension (not in the reference): z [B,T,C] padded to the longest utterance + per-utterance frame counts -> wav [B,1,T*hop] with
+        zeros beyond each utterance's samples; every utterance as if it were decoded alone (include/lds.h lds_vocoder_forward_ragged)"""
+        return self.forward(z, _lengths=lengths)
+
+    @torch.no_grad()
+    def forward(self, z, _lengths=None):
         if not z.is_cuda:
             raise RuntimeError("Hifi_VAEGAN.forward needs tensors on a HIP device (no CPU fallback)")
         if self.decoder_model is None:
@@ -51,4 +57,4 @@ class Hifi_VAEGAN(torch.nn.Module):
             self.decoder_model = native.Generator(self.h, state)     # folds weight norm like remove_weight_norm()
             self._state = None
         zt = native.transpose(z.contiguous().float())                # z.transpose(-1,-2) -> [B,C,T]
-        return self.decoder_model.forward(zt)
+        return self.decoder_model.forward(zt, _lengths)

@@ -51,7 +51,7 @@ EXPORTS = [
     "lds_embed_workspace_bytes", "lds_embed_forward", "lds_transpose", "lds_gather_rows", "lds_resample_frames", "lds_axpby", "lds_vocoder_create", "lds_vocoder_destroy",
     "lds_vocoder_workspace_bytes", "lds_vocoder_forward", "lds_lm_create", "lds_lm_destroy", "lds_lm_workspace_bytes", "lds_lm_encode",
     "lds_lm_generate", "lds_prof_enable", "lds_prof_summary", "lds_unet_set_gemm_mode", "lds_unet_get_gemm_mode",
-    "lds_unet_set_latency_mode", "lds_unet_get_latency_mode", "lds_unet_forward_ragged", "lds_sampler_run_ragged"]
+    "lds_unet_set_latency_mode", "lds_unet_get_latency_mode", "lds_unet_forward_ragged", "lds_sampler_run_ragged", "lds_vocoder_forward_ragged"]
 # include/lds_test.h: single-op entry points for tests/ and tools/ (not part of the drop-in boundary)
 TEST_EXPORTS = [
     "lds_test_conv", "lds_test_dconv", "lds_bench_dconv", "lds_test_gn_apply", "lds_bench_gn_stream", "lds_test_gn_chain_k4p",
@@ -338,8 +338,8 @@ class Generator:
             _lib.lds_vocoder_destroy(self.h)
             self.h = None
 
-    def forward(self, z):
-        """z [B,C,T] -> wav [B,1,T*hop]"""
+    def forward(self, z, lengths=None):
+        """z [B,C,T] -> wav [B,1,T*hop]; lengths: the utterances' own frame counts (ragged batch, include/lds.h lds_vocoder_forward_ragged)"""
         import torch
         B, Cc, T = z.shape
         assert Cc == self.C
@@ -347,6 +347,11 @@ class Generator:
         check(lib().lds_vocoder_workspace_bytes(self.h, B, T, C.byref(nb)))
         ws = self.ws.get(nb.value, z.device)
         wav = torch.empty(B, 1, T * self.hop, dtype=torch.float32, device=z.device)
+        if lengths is not None:
+            ln = UNet._lengths(lengths, B, T)
+            check(lib().lds_vocoder_forward_ragged(self.h, _dev(z, torch.float32), C.c_void_p(ln.ctypes.data), _dev(wav), _dev(ws), C.c_size_t(ws.numel()),
+                                                   B, T, _stream()))
+            return wav
         check(lib().lds_vocoder_forward(self.h, _dev(z, torch.float32), _dev(wav), _dev(ws), C.c_size_t(ws.numel()), B, T,
                                         _stream()))
         return wav

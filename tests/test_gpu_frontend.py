@@ -265,11 +265,12 @@ def test_ragged_masked_batch_equals_utterances_alone():
     def noise(idx_list, T):
         return torch.stack([torch.from_numpy(init_weights.uniform(f"masked.xT.{i}", (1, 80, T), 3, -1.7, 1.7)) for i in idx_list]).cuda()
     seq = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise)
-    msk = infer_tts.synthesize_ragged_masked(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise, streams=2, max_batch=4)
-    torch.cuda.synchronize()
-    for (m0, w0), (m1, w1), n in zip(seq, msk, lens):
-        assert m1.shape == (n, 80) and w1.shape == (n * 512,)
-        assert relmax(m1.cpu().numpy(), m0.cpu().numpy()) < 1e-4 and relmax(w1.cpu().numpy(), w0.cpu().numpy()) < 1e-4
+    for ragged_voc in (True, False):
+        msk = infer_tts.synthesize_ragged_masked(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise, streams=2, max_batch=4, ragged_vocoder=ragged_voc)
+        torch.cuda.synchronize()
+        for (m0, w0), (m1, w1), n in zip(seq, msk, lens):
+            assert m1.shape == (n, 80) and w1.shape == (n * 512,)
+            assert relmax(m1.cpu().numpy(), m0.cpu().numpy()) < 1e-4 and relmax(w1.cpu().numpy(), w0.cpu().numpy()) < 1e-4
 
 
 def test_roformer_generate_bench_size_vs_oracle(lm_gpu):

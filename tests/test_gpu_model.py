@@ -486,3 +486,24 @@ def test_ragged_sampler_vs_alone(unit2mel_gpu, monkeypatch, method, speedup, rec
         worst = max(worst, relmax(y[b:b + 1, :n].cpu().numpy(), alone.cpu().numpy()))
         assert n == T or float(y[b, n:].abs().max()) == 0.0
     record_margin(worst, 1e-4)
+
+
+@pytest.mark.parametrize("T,lens", [(40, [40, 24, 33]), (96, [17, 96, 60, 1])])
+def test_ragged_vocoder_vs_alone(T, lens, record_margin):
+    """lds_vocoder_forward_ragged: a padded batch of latents with garbage beyond each length; every utterance's samples against the
+    utterance decoded alone, zeros beyond"""
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights
+    h = arch.SYNTHETIC_VOCODER_H
+    voc = Hifi_VAEGAN(None, device="cuda", h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
+    B = len(lens)
+    z = dev(init_weights.uniform(f"ragv.{T}", (B, T, h["inter_channels"]), 81, -1.5, 1.5))
+    wav = voc.forward_ragged(z, lens)
+    hop = h["hop_size"]
+    assert wav.shape == (B, 1, T * hop) and torch.isfinite(wav).all()
+    worst = 0.0
+    for b, n in enumerate(lens):
+        alone = voc(z[b:b + 1, :n].contiguous())
+        worst = max(worst, relmax(wav[b:b + 1, :, :n * hop].cpu().numpy(), alone.cpu().numpy()))
+        assert n == T or float(wav[b, :, n * hop:].abs().max()) == 0.0
+    record_margin(worst, 1e-4)
