@@ -251,6 +251,18 @@ def test_ragged_buckets_on_streams_equal_sequential(threads):
     torch.cuda.synchronize()
     for a, b in zip(seq, par):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # the same in latency mode: the cluster split-K's partial tiles and arrival counters live in the per-stream workspaces, and the
+    # fixed-order sum makes a bucket's result independent of what runs beside it
+    unet = svc.model.decoder.denoise_fn
+    unet.set_latency_mode(True)
+    try:
+        seq = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise)
+        par = infer_tts.synthesize_ragged(svc, codebook, rows, 1, 250, "dpm-solver", noise_fn=noise, streams=3)
+        torch.cuda.synchronize()
+    finally:
+        unet.set_latency_mode(False)
+    for a, b in zip(seq, par):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_ragged_masked_batch_equals_utterances_alone():

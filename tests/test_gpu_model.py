@@ -467,6 +467,30 @@ def test_ragged_unet_forward_vs_alone(unit2mel_gpu, unet_weights, T, lens, laten
         unet.set_latency_mode(False)
 
 
+def test_ragged_ddpm_vs_alone(unit2mel_gpu, monkeypatch, record_margin):
+    """the ancestral sampler on a ragged batch (one noise draw per step, padded like the state): 12 steps, every utterance against its own run"""
+    from lds import init_weights
+    gd = unit2mel_gpu.decoder
+    T, lens, K = 64, [64, 37], 12
+    B = len(lens)
+    cond = init_weights.uniform("rag.d.cond", (B, T, 256), 73, -1, 1)
+    draws = init_weights.uniform("rag.d.noise", (K + 1, B, 1, 80, T), 74, -1.7, 1.7)
+    gd.k_step = K
+    try:
+        q = [dev(d) for d in draws]
+        monkeypatch.setattr(torch, "randn", lambda *a, **k: q.pop(0))
+        y = gd.forward_ragged(dev(cond), lens, infer_speedup=1, method=None)
+        worst = 0.0
+        for b, n in enumerate(lens):
+            q = [dev(np.ascontiguousarray(d[b:b + 1, :, :, :n])) for d in draws]
+            monkeypatch.setattr(torch, "randn", lambda *a, **k: q.pop(0))
+            alone = gd(dev(np.ascontiguousarray(cond[b:b + 1, :n])), infer=True, infer_speedup=1, method=None)
+            worst = max(worst, relmax(y[b:b + 1, :n].cpu().numpy(), alone.cpu().numpy()))
+    finally:
+        gd.k_step = 1000
+    record_margin(worst, 1e-4)
+
+
 @pytest.mark.parametrize("method,speedup", [("dpm-solver", 250), ("unipc", 250), ("ddim", 250)])
 def test_ragged_sampler_vs_alone(unit2mel_gpu, monkeypatch, method, speedup, record_margin):
     """GaussianDiffusion.forward_ragged: a padded batch of three lengths through a 4-step run, every utterance against its own run alone"""
