@@ -43,10 +43,13 @@ class Hifi_VAEGAN(torch.nn.Module):
     def forward_ragged(self, z, lengths):
         """Extension (not in the reference): z [B,T,C] padded to the longest utterance + per-utterance frame counts -> wav [B,1,T*hop] with
         zeros beyond each utterance's samples; every utterance as if it were decoded alone (include/lds.h lds_vocoder_forward_ragged)"""
-        return self.forward(z, _lengths=lengths)
+        return self._decode(z, lengths)
 
     @torch.no_grad()
-    def forward(self, z, _lengths=None):
+    def forward(self, z):
+        return self._decode(z, None)
+
+    def _decode(self, z, _lengths):
         if not z.is_cuda:
             raise RuntimeError("Hifi_VAEGAN.forward needs tensors on a HIP device (no CPU fallback)")
         if self.decoder_model is None:
