@@ -50,6 +50,11 @@ int lds_bench_gn_stream(int C1, int C2, int T, int B, int iters, float* ms_out, 
 int lds_test_gn_fold_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps, int groups,
                          const float* w2, const float* bias2, float* mid, float* out, int B, int C, int Cm, int Co, int T, int cfg, int tile_batch,
                          void* stream);
+/* the same through either kernel family (fmt -1 = exact fp32 K4P, 0 = three bf16 planes, 1 = two fp16 planes); the folded launch runs `reps` times
+ * on the same inputs into out[rep][B][Co][T]: every repetition must equal the first bit for bit, also when workgroups share a CU */
+int lds_test_gn_fold_split(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps, int groups,
+                           const float* w2, const float* bias2, float* mid, float* out, int B, int C, int Cm, int Co, int T, int cfg, int tile_batch,
+                           int fmt, int reps, void* stream);
 /* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
  * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
 int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,
@@ -95,6 +100,20 @@ int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, voi
 /* GroupNorm(+scale/shift)(+SiLU) through the K8B3 streaming pass (statistics from gn_partials_bf3) */
 int lds_test_gn_apply_bf3(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                           const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
+
+/* ---- debugging aids (tests/test_gpu_poison.py, tools/diag_trace.py) ----------------------------------------------------------
+ * lds_debug_fill_u32: every 32-bit word of a device buffer = pattern.  Tests fill a caller workspace with NaN patterns (0x7fc07fc0 is a NaN
+ * as fp32 and as two fp16 / bf16 halves) before a call: a kernel that reads a slot no kernel of THAT call wrote turns it into a NaN (or, behind
+ * a select, into a result that differs from the zero-filled run's).
+ * lds_debug_trace(1): clear the records and, while on, make every lds_unet_forward synchronise after each stage and keep a host copy of the
+ * stage's output tensor (names "down0.res1.conv1", "mid.tfm.att2", ...; activation tensors in the handle's layout: K4P fp32, or split planes
+ * [B][C/8][planes][T+2][8] 16-bit); lds_debug_trace(0) stops recording and keeps the records for lds_debug_trace_get.  Process-global. */
+int lds_debug_fill_u32(void* dev, size_t n_words, uint32_t pattern, void* stream);
+/* the workspace plan of lds_unet_forward(B, T) as text, one slot per line: "name offset bytes" */
+int lds_debug_unet_plan(const lds_unet* u, int B, int T, char* buf, size_t cap);
+int lds_debug_trace(int on);
+int lds_debug_trace_count(void);
+int lds_debug_trace_get(int i, char* name, size_t name_cap, const void** data, size_t* bytes);
 
 #ifdef __cplusplus
 }

@@ -273,7 +273,7 @@ struct Bf3Kernel {
             float rs = 1.f, sd = 1.f, rm = 0.f;
             if (g < G_) {
                 float mu, var;
-                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
+                gnf_group_stats(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
                 sd = sqrtf(var + p.gnf_eps); rs = 1.0f / sd; rm = rs * mu;
             }
             if (lane == 0) { tail[g] = rs; tail[8 + g] = sd; tail[16 + g] = rm; }

@@ -337,7 +337,7 @@ struct DmaKernel {
             float rs = 1.f, rm = 0.f;      // (slots of absent groups: finite, they multiply zeros)
             if (g < G_) {
                 float mu, var;
-                gn_group_finish(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
+                gnf_group_stats(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
                 rs = 1.0f / sqrtf(var + p.gnf_eps); rm = rs * mu;
             }
             if (lane == 0) { tail[g] = rs; tail[8 + g] = rm; }

@@ -65,4 +65,50 @@ static __device__ __forceinline__ void gn_group_finish(const float2* __restrict_
           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n), 63));
 }
 
+// ---- the GroupNorm FOLD's statistics (conv_dma.hip / conv_bf3.hip gnf_prepare) -----------------------------------------------------------
+// The same (mean, variance) from the same partials, combined as two plain wave sums instead of a Chan tree:
+//     mean = sum_i n_i mean_i / N,      var = sum_i (M2_i + n_i (mean_i - mean)^2) / N,      N = 16 cg16 Tv  (known without a reduction)
+// Every cross-lane step is ONE add of a value that was complete before the step (no reciprocal, no compare / select, no packed arithmetic
+// between the steps), each behind an explicit pad of wait states.  Why: round 4 found the Chan tree's result inside conv_bf3<32,64,..,BK 64,
+// F16, GNF> -- and only there, and only in workgroups that share their CU with another one -- differing between launches on identical inputs
+// (the lane-63 chain took one step with a zero weight; every recompilation that moved the code hid it).  The order of
+// the additions is fixed, so the result is a function of the partials alone.
+static __device__ __forceinline__ float gnf_wave_sum(float v) {      // total in every lane's copy of lane 63 -> returned wave-uniform
+#define LDS_GNF_STEP(CTRL, RM, BC)                                                                                                        \
+    {                                                                                                                                     \
+        asm volatile("s_nop 3" : "+v"(v));                                                                                                \
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, BC));                    \
+    }
+    LDS_GNF_STEP(0x111, 0xf, true)       // row_shr:1
+    LDS_GNF_STEP(0x112, 0xf, true)       // row_shr:2
+    LDS_GNF_STEP(0x114, 0xf, true)       // row_shr:4
+    LDS_GNF_STEP(0x118, 0xf, true)       // row_shr:8    lane 15 of every row = the row's sum
+    LDS_GNF_STEP(0x142, 0xa, false)      // row_bcast:15 into rows 1 and 3
+    LDS_GNF_STEP(0x143, 0xc, false)      // row_bcast:31 into rows 2 and 3: lane 63 = the wave's sum
+#undef LDS_GNF_STEP
+    asm volatile("s_nop 3" : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// `first` = this lane's partial of round 0 (gn_part_load, requested early); groups of more than 64 partials (T > 1024 at 32 channels per group)
+// load the further rounds here, once per pass
+static __device__ __forceinline__ void gnf_group_stats(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, GnPart first, float& mu,
+                                                       float& var, int Tv) {
+    const int nT = (T + 31) >> 5, P = cg16 * nT;
+    const float N = 16.0f * (float)cg16 * (float)Tv;
+    float s1 = first.n * first.mean;
+    for (int p0 = 64; p0 < P; p0 += 64) {
+        const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0, Tv);
+        s1 = fmaf(q.n, q.mean, s1);
+    }
+    mu = gnf_wave_sum(s1) / N;
+    float d = first.mean - mu;
+    float s2 = fmaf(first.n * d, d, first.m2);      // (an empty partial: n = mean = M2 = 0 contributes 0)
+    for (int p0 = 64; p0 < P; p0 += 64) {
+        const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0, Tv);
+        d = q.mean - mu;
+        s2 += fmaf(q.n * d, d, q.m2);
+    }
+    var = gnf_wave_sum(s2) / N;
+}
+
 }  // namespace lds

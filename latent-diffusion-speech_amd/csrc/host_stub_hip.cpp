@@ -29,6 +29,10 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;
 }
+hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t) {
+    for (size_t i = 0; i < count; ++i) memcpy((char*)d + 4 * i, &v, 4);
+    return hipSuccess;
+}
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipGetDevice(int* d) {
     *d = 0;

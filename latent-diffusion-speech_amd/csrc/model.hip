@@ -391,11 +391,13 @@ static bool pack_convT(Owner& o, const float* w, const float* b, int Ci, int Co,
 // ------------------------------------------------------------------------------------------------
 struct Arena {
     char* base; size_t cap; size_t used = 0; bool ok = true;
+    std::vector<std::pair<std::string, std::pair<size_t, size_t>>>* log = nullptr;      // (name, (offset, bytes)) of every slot: lds_debug_unet_plan
     Arena(void* p, size_t n) : base((char*)p), cap(n) {}
-    float* f(size_t n_floats) {
+    float* f(size_t n_floats, const char* name = nullptr) {
         size_t bytes = (n_floats * sizeof(float) + 255) & ~(size_t)255;
         if (base && used + bytes > cap) ok = false;
         char* p = base ? base + used : nullptr;
+        if (log) log->push_back({name ? name : "slot" + std::to_string(log->size()), {used, bytes}});
         used += bytes;
         return (float*)p;
     }
@@ -504,6 +506,50 @@ struct TileBatchScope {
     }
     ~TileBatchScope() { tl_tile_batch = prev; tl_kpart = pp; tl_kcount = pc; }
 };
+
+// Debug trace (include/lds_test.h lds_debug_trace): while on, a UNet forward synchronises after every stage and keeps a host copy of the
+// stage's output tensor, so that two runs (two modes, two workspace fill patterns) can be compared stage by stage.  Off in the product path:
+// a forward then only reads the atomic flag.
+static std::atomic<int> g_trace_on{0};
+struct TraceRec { std::string name; std::vector<char> bytes; };
+static std::mutex g_trace_mu;
+static std::vector<TraceRec> g_trace;
+static thread_local std::string tl_trace_stage;
+static int trace_out(hipStream_t st, const char* what, const void* dev, size_t bytes) {
+    if (!g_trace_on.load(std::memory_order_relaxed)) return LDS_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    TraceRec r;
+    r.name = tl_trace_stage + "." + what;
+    r.bytes.resize(bytes);
+    HIP_TRY(hipMemcpy(r.bytes.data(), dev, bytes, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace.push_back(std::move(r));
+    return LDS_OK;
+}
+extern "C" int lds_debug_trace(int on) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (on) g_trace.clear();
+    g_trace_on.store(on ? 1 : 0);
+    return LDS_OK;
+}
+extern "C" int lds_debug_trace_count(void) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    return (int)g_trace.size();
+}
+extern "C" int lds_debug_trace_get(int i, char* name, size_t name_cap, const void** data, size_t* bytes) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (i < 0 || i >= (int)g_trace.size() || !name || !data || !bytes || name_cap == 0) return fail(LDS_EINVAL, "bad argument");
+    snprintf(name, name_cap, "%s", g_trace[i].name.c_str());
+    *data = g_trace[i].bytes.data();
+    *bytes = g_trace[i].bytes.size();
+    return LDS_OK;
+}
+// every 32-bit word of a device buffer = pattern (tests poison a workspace with NaN patterns: a kernel that reads what no kernel of the call wrote shows)
+extern "C" int lds_debug_fill_u32(void* dev, size_t n_words, uint32_t pattern, void* stream) {
+    if (!dev) return fail(LDS_EINVAL, "bad argument");
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dev, (int)pattern, n_words, (hipStream_t)stream));
+    return LDS_OK;
+}
 
 static int fill_dconv(const ConvW& W, const float* x1, int C1, const float* x2, int C2, int Tsrc, const DOpt& o, float* out, int B, DmaConvArgs& a) {
     memset(&a, 0, sizeof(a));
@@ -1059,11 +1105,11 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     auto k4 = [bf3](int C, int Tl) -> size_t { return bf3 ? split_floats(bf3 - 1, C, Tl) : (size_t)C * (Tl + 2); };
     const int nb = u->cfg.n_blocks, L = u->cfg.n_layers;
     const int* boc = u->cfg.block_out_channels;
-    w.e1 = A.f((size_t)B * u->temb);
-    w.emb = A.f((size_t)B * u->temb);
-    w.tproj = A.f((size_t)B * u->tp_M);
-    w.xin = A.f(B * k4(u->M + u->H, T));
-    w.xk = A.f(B * k4(u->M, T)); w.ck = A.f(B * k4(u->H, T)); w.cinc = A.f(B * k4(u->conv_in.Co, T));
+    w.e1 = A.f((size_t)B * u->temb, "e1");
+    w.emb = A.f((size_t)B * u->temb, "emb");
+    w.tproj = A.f((size_t)B * u->tp_M, "tproj");
+    w.xin = A.f(B * k4(u->M + u->H, T), "xin");
+    w.xk = A.f(B * k4(u->M, T), "xk"); w.ck = A.f(B * k4(u->H, T), "ck"); w.cinc = A.f(B * k4(u->conv_in.Co, T), "cinc");
     std::vector<int> Ts{T};
     for (int i = 0; i < nb - 1; ++i) Ts.push_back(down_len(Ts.back()));
     size_t maxct = 0, maxgn = k4(boc[0], T), maxatt = 0;      // k4(C, T) = C * (T + 2) also covers the VT layout's C * ceil4(T) up to C floats
@@ -1071,8 +1117,9 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
     auto gpn = [](int C, int Tl) { return (size_t)(C / 16) * ((Tl + 31) / 32) * 2; };
     w.gpart.clear();
     auto act = [&](int C, int Tl) {                            // an exactly-sized activation buffer + its partials
-        float* p = A.f(B * k4(C, Tl));
-        w.gpart[p] = (float2*)A.f(B * gpn(C, Tl));
+        const std::string nm = "skip" + std::to_string(w.gpart.size());
+        float* p = A.f(B * k4(C, Tl), nm.c_str());
+        w.gpart[p] = (float2*)A.f(B * gpn(C, Tl), (nm + ".gnpart").c_str());
         return p;
     };
     w.skips.clear();
@@ -1102,21 +1149,36 @@ static void plan_ws(const lds_unet* u, Arena& A, int B, int T, UnetWs& w) {
             prev = co;
         }
     }
-    auto scratch = [&]() {                                     // a maximum-sized activation buffer + its partials
-        float* p = A.f(B * maxct);
-        w.gpart[p] = (float2*)A.f(B * maxgp);
+    auto scratch = [&](const char* nm) {                       // a maximum-sized activation buffer + its partials
+        float* p = A.f(B * maxct, nm);
+        w.gpart[p] = (float2*)A.f(B * maxgp, (std::string(nm) + ".gnpart").c_str());
         return p;
     };
-    w.cur[0] = scratch(); w.cur[1] = scratch();
-    w.r = scratch(); w.h1 = scratch(); w.sc = A.f(B * maxct);
-    w.ta = A.f(B * maxct); w.tb = A.f(B * maxct); w.upt = A.f(B * maxct);
-    w.gno = A.f(B * maxgn);
-    w.qk = A.f(B * maxatt * 2); w.v = A.f(B * (maxatt + 2048)); w.att = A.f(B * maxatt); w.ff = A.f(B * maxatt * 4);
-    w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2);
-    w.lens_dev = (int*)A.f(64);
-    w.kpart = u->latency_mode ? A.f(kClusterPartFloats) : nullptr;
-    w.kcount = u->latency_mode ? (unsigned*)A.f(kClusterCounters) : nullptr;
-    A.f(16384);   // tail slack: ragged last tiles read (masked) entries past a tensor's end
+    w.cur[0] = scratch("cur0"); w.cur[1] = scratch("cur1");
+    w.r = scratch("r"); w.h1 = scratch("h1"); w.sc = A.f(B * maxct, "sc");
+    w.ta = A.f(B * maxct, "ta"); w.tb = A.f(B * maxct, "tb"); w.upt = A.f(B * maxct, "upt");
+    w.gno = A.f(B * maxgn, "gno");
+    w.qk = A.f(B * maxatt * 2, "qk"); w.v = A.f(B * (maxatt + 2048), "v"); w.att = A.f(B * maxatt, "att"); w.ff = A.f(B * maxatt * 4, "ff");
+    w.lnp = (float2*)A.f(B * (maxatt / 32 + 64) * 2, "lnp");
+    w.lens_dev = (int*)A.f(64, "lens");
+    w.kpart = u->latency_mode ? A.f(kClusterPartFloats, "kpart") : nullptr;
+    w.kcount = u->latency_mode ? (unsigned*)A.f(kClusterCounters, "kcount") : nullptr;
+    A.f(16384, "tail_slack");   // tail slack: ragged last tiles read (masked) entries past a tensor's end
+}
+
+// the workspace plan of a forward as text, one slot per line: "name offset bytes" (tools/diag_poison.py fills one slot at a time)
+extern "C" int lds_debug_unet_plan(const lds_unet* u, int B, int T, char* buf, size_t cap) {
+    if (!u || !buf || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    std::vector<std::pair<std::string, std::pair<size_t, size_t>>> log;
+    Arena A(nullptr, 0);
+    A.log = &log;
+    UnetWs w;
+    plan_ws(u, A, B, T, w);
+    std::string out;
+    for (auto& e : log) out += e.first + " " + std::to_string(e.second.first) + " " + std::to_string(e.second.second) + "\n";
+    if (out.size() + 1 > cap) return fail(LDS_ENOMEM, "plan needs %zu bytes", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return LDS_OK;
 }
 
 extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t* out) {
@@ -1128,6 +1190,21 @@ extern "C" int lds_unet_workspace_bytes(const lds_unet* u, int B, int T, size_t*
     return LDS_OK;
 }
 
+// bytes of one activation tensor [B][C][T] between kernels in the handle's GEMM mode (K4P fp32 or split planes): the debug trace's copies
+static size_t act_bytes(const lds_unet* u, int B, int C, int T) {
+    return sizeof(float) * (size_t)B * (u->gemm_mode ? split_floats(u->gemm_mode - 1, C, T) : (size_t)C * (T + 2));
+}
+#define TRACE(what, ptr, bytes) LDS_TRY(trace_out(st, what, ptr, bytes))
+// an activation tensor in the handle's layout; the record's name carries what a reader needs to decode it: "stage.what|C|T|mode"
+#define TRACE_ACT(what, ptr, C_, T_)                                                                                  \
+    do {                                                                                                              \
+        if (g_trace_on.load(std::memory_order_relaxed)) {                                                             \
+            char nm_[64];                                                                                             \
+            snprintf(nm_, sizeof(nm_), "%s|%d|%d|%d", what, (int)(C_), (int)(T_), u->gemm_mode);                      \
+            LDS_TRY(trace_out(st, nm_, ptr, act_bytes(u, B, C_, T_)));                                                \
+        }                                                                                                             \
+    } while (0)
+
 static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, const float* x1, int C1, const float* x2, int C2, int T,
                       float* out, int B, hipStream_t st, int lvl = 0) {
     // reference resnet.py:591-641 (scale_shift): GN -> SiLU -> conv1 -> GN -> *(1+scale)+shift -> SiLU -> conv2 -> + shortcut.
@@ -1138,13 +1215,17 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     DOpt o1;
     o1.lvl_in = o1.lvl_out = lvl;
     o1.pad = 1; o1.gnpart_out = w.gp(w.h1);
+    TRACE_ACT("gn1", w.gno, C1 + C2, T);
     LDS_TRY(dconv_any(bf3, r.conv1, w.gno, C1 + C2, nullptr, 0, T, o1, w.h1, B, st));
+    TRACE_ACT("conv1", w.h1, r.cout, T);
     HIP_TRY(gn_any(bf3, w.h1, nullptr, r.cout, 0, T, u->G, 1e-5f, r.g2, r.b2, w.tproj, w.ss_stride, r.temb_off, 1, w.gp(w.h1), nullptr, w.gno, B, st, lvl));
+    TRACE_ACT("gn2", w.gno, r.cout, T);
     const float* res = x1;
     if (r.has_sc) {
         // the shortcut rides in conv2's launch (second reduction into the same accumulators; skip-concat on read: two source pointers)
         const int rc = bf3 ? run_dconv_pair_bf3(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, bf3 - 1, lvl)
                            : run_dconv_pair(r.conv2, w.gno, r.sc, x1, C1, x2, C2, T, r.bias_pair, w.gp(out), out, B, st, lvl);
+        if (rc == LDS_OK) TRACE_ACT("conv2sc", out, r.cout, T);
         if (rc != 1) return rc;
         DOpt os;      // no fused variant for these shapes: two launches
         os.lvl_in = os.lvl_out = lvl;
@@ -1154,7 +1235,9 @@ static int run_resnet(const lds_unet* u, const ResnetW& r, const UnetWs& w, cons
     DOpt o2;
     o2.lvl_in = o2.lvl_out = lvl;
     o2.pad = 1; o2.res = res; o2.gnpart_out = w.gp(out);
-    return dconv_any(bf3, r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st);
+    LDS_TRY(dconv_any(bf3, r.conv2, w.gno, r.cout, nullptr, 0, T, o2, out, B, st));
+    TRACE_ACT("conv2", out, r.cout, T);
+    return LDS_OK;
 }
 
 static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const float* x, int T, float* out, int B, hipStream_t st, int lvl = 0) {
@@ -1175,6 +1258,7 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         HIP_TRY(gn_any(bf3, x, nullptr, C, 0, T, u->G, 1e-6f, t.gn_g, t.gn_b, nullptr, 0, 0, 0, w.gp(x), nullptr, w.gno, B, st, lvl));
         LDS_TRY(dconv_any(bf3, t.proj_in, w.gno, C, nullptr, 0, T, op, w.ta, B, st));
     }
+    TRACE_ACT("proj_in", w.ta, C, T);
     float* h = w.ta;
     float* hn = w.tb;
     for (int a = 0; a < 2; ++a) {
@@ -1184,12 +1268,16 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
         oq.ln_part = w.lnp; oq.ln_np = C / 32; oq.ln_c1 = t.qkv_c1[a]; oq.ln_c2 = t.qkv_c2[a];   // LayerNorm folded into the epilogue
         oq.out_f32 = bf3 ? 1 : 0;                                          // (split-bf16 mode: q / k / v stay fp32 for the attention kernel)
         LDS_TRY(dconv_any(bf3, t.qkv[a], h, C, nullptr, 0, T, oq, w.qk, B, st));
+        TRACE(a ? "qk2" : "qk1", w.qk, sizeof(float) * (size_t)B * 2 * C * (T + 2));
+        TRACE(a ? "v2" : "v1", w.v, sizeof(float) * (size_t)B * C * ((T + 3) & ~3));
         if (bf3) HIP_TRY(launch_attention_k4p_out_bf3(w.qk, w.v, w.att, B, C, T, u->heads, st, bf3 - 1, tl_tile_batch, tl_lens, lvl));
         else HIP_TRY(launch_attention_k4p(w.qk, w.v, w.att, B, C, T, u->heads, st, tl_tile_batch, tl_lens, lvl));
         DOpt oo;
         oo.lvl_in = oo.lvl_out = lvl;
         oo.res = h; oo.lnpart_out = w.lnp;
+        TRACE_ACT(a ? "att2" : "att1", w.att, C, T);
         LDS_TRY(dconv_any(bf3, t.o[a], w.att, C, nullptr, 0, T, oo, hn, B, st));
+        TRACE_ACT(a ? "o2" : "o1", hn, C, T);
         float* tmp = h; h = hn; hn = tmp;
     }
     DOpt of;
@@ -1197,10 +1285,13 @@ static int run_tfm(const lds_unet* u, const TfmW& t, const UnetWs& w, const floa
     of.epi = EPI_GEGLU;
     of.ln_part = w.lnp; of.ln_np = C / 32; of.ln_c1 = t.ff1_c1; of.ln_c2 = t.ff1_c2;
     LDS_TRY(dconv_any(bf3, t.ff1, h, C, nullptr, 0, T, of, w.ff, B, st));
+    TRACE_ACT("ff1", w.ff, 4 * C, T);
     DOpt o2;      // ff.net.2 + residual + proj_out + residual in one launch (load_tfm: ff2_out)
     o2.lvl_in = o2.lvl_out = lvl;
     o2.res = x; o2.gnpart_out = w.gp(out);
-    return dconv_any(bf3, t.ff2_out, w.ff, 4 * C, h, C, T, o2, out, B, st);
+    LDS_TRY(dconv_any(bf3, t.ff2_out, w.ff, 4 * C, h, C, T, o2, out, B, st));
+    TRACE_ACT("ff2_out", out, C, T);
+    return LDS_OK;
 }
 
 // Ragged batches: per-utterance lengths (host int32 [B], 1 <= len <= T; null = none) -> the workspace's device copy, carried in a launch's
@@ -1289,6 +1380,10 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
         o.pad = 1; o.gnpart_out = w.gp(w.skips[si]);
         LDS_TRY(dconv_any(bf3, u->conv_in, w.xin, cin, nullptr, 0, T, o, w.skips[si], B, st));
     }
+    const bool tr = g_trace_on.load(std::memory_order_relaxed) != 0;
+    auto stage = [&](const char* fmt, int i, int j) { if (tr) { char nm[48]; snprintf(nm, sizeof(nm), fmt, i, j); tl_trace_stage = nm; } };
+    stage("conv_in", 0, 0);
+    TRACE_ACT("out", w.skips[si], u->conv_in.Co, T);
     const float* cur = w.skips[si++];
     int Tl = T, lvl = 0;      // lvl: how many stride-2 convolutions lie between the input and this resolution (ragged batches, k4p.h)
     std::vector<int> skipT{T};
@@ -1297,7 +1392,9 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
         for (size_t j = 0; j < d.res.size(); ++j) {
             float* dst = w.skips[si];
             const bool att = !d.att.empty();
+            stage("down%d.res%d", i, (int)j);
             LDS_TRY(run_resnet(u, d.res[j], w, cur, d.res[j].cin, nullptr, 0, Tl, att ? w.r : dst, B, st, lvl));
+            stage("down%d.tfm%d", i, (int)j);
             if (att) LDS_TRY(run_tfm(u, d.att[j], w, w.r, Tl, dst, B, st, lvl));
             cur = dst;
             ++si;
@@ -1309,13 +1406,18 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             o.pad = 1; o.stride = 2; o.gnpart_out = w.gp(w.skips[si]);
             LDS_TRY(dconv_any(bf3, d.down, cur, d.ch, nullptr, 0, Tl, o, w.skips[si], B, st));
             Tl = down_len(Tl);
+            stage("down%d.downsample", i, 0);
+            TRACE_ACT("out", w.skips[si], d.ch, Tl);
             ++lvl;
             cur = w.skips[si++];
             skipT.push_back(Tl);
         }
     }
+    stage("mid.res0", 0, 0);
     LDS_TRY(run_resnet(u, u->mid_r0, w, cur, u->mid_r0.cin, nullptr, 0, Tl, w.cur[0], B, st, lvl));
+    stage("mid.tfm", 0, 0);
     LDS_TRY(run_tfm(u, u->mid_t, w, w.cur[0], Tl, w.cur[1], B, st, lvl));
+    stage("mid.res1", 0, 0);
     LDS_TRY(run_resnet(u, u->mid_r1, w, w.cur[1], u->mid_r1.cin, nullptr, 0, Tl, w.cur[0], B, st, lvl));
     cur = w.cur[0];
     int ci = 0;  // index of the buffer `cur` lives in
@@ -1328,7 +1430,9 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             const int hin = b.res[j].cin - b.skip_ch[j];
             const bool att = !b.att.empty();
             float* dst = w.cur[ci ^ 1];
+            stage("up%d.res%d", i, (int)j);
             LDS_TRY(run_resnet(u, b.res[j], w, cur, hin, skip, b.skip_ch[j], Tl, att ? w.r : dst, B, st, lvl));
+            stage("up%d.tfm%d", i, (int)j);
             if (att) LDS_TRY(run_tfm(u, b.att[j], w, w.r, Tl, dst, B, st, lvl));
             cur = dst;
             ci ^= 1;
@@ -1354,6 +1458,8 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
             }
             Tl = Tn;
             --lvl;
+            stage("up%d.upsample", i, 0);
+            TRACE_ACT("out", dst, b.ch, Tl);
             cur = dst;
             ci ^= 1;
         }
@@ -1361,9 +1467,13 @@ static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, con
     // out: GN -> SiLU -> conv k3 (reference unet_1d_condition.py:1028-1031); eps leaves in the caller's frame-major layout
     const int c0 = u->cfg.block_out_channels[0];
     HIP_TRY(gn_any(bf3, cur, nullptr, c0, 0, Tl, u->G, 1e-5f, u->gno_g, u->gno_b, nullptr, 0, 0, 1, w.gp(cur), nullptr, w.gno, B, st, 0));
+    stage("out", 0, 0);
+    TRACE_ACT("gn", w.gno, c0, Tl);
     DOpt o;
     o.pad = 1; o.out_plain = 1;
-    return dconv_any(bf3, u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st);
+    LDS_TRY(dconv_any(bf3, u->conv_out, w.gno, c0, nullptr, 0, Tl, o, eps, B, st));
+    TRACE("eps", eps, sizeof(float) * (size_t)B * u->M * Tl);
+    return LDS_OK;
 }
 
 extern "C" int lds_unet_forward(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
@@ -2184,6 +2294,53 @@ extern "C" int lds_test_gn_fold_k4p(const float* x, const float* w1, const float
     }
     HIP_TRY(launch_from_k4p(km, mid, B, Cm, T, st));
     HIP_TRY(launch_from_k4p(ko, out, B, Co, T, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
+// the same through either kernel family (fmt -1 = exact fp32 / K4P, conv_dma.hip; 0 = three bf16 planes, 1 = two fp16 planes, conv_bf3.hip).  reps >= 1:
+// the folded launch runs `reps` times on the same inputs into out[rep][B][Co][T] -- a determinism check: every repetition must equal the first
+// bit for bit, also when several workgroups share a CU.
+extern "C" int lds_test_gn_fold_split(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps, int groups,
+                                      const float* w2, const float* bias2, float* mid, float* out, int B, int C, int Cm, int Co, int T, int cfg, int tile_batch,
+                                      int fmt, int reps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !w1 || !w2 || !mid || !out || (fmt != -1 && fmt != FMT_BF16X3 && fmt != FMT_F16X2) || reps < 1) return fail(LDS_EINVAL, "bad argument");
+    const bool f32 = fmt < 0;
+    Owner own;
+    TmpDev tmp;
+    ConvW W1, W2;
+    float *cg = nullptr, *c2 = nullptr;
+    if (!pack_conv(own, w1, bias1, Cm, C, 1, W1) || !pack_gn_fold(own, w2, bias2, gamma, beta, Co, Cm, groups, W2, cg, c2)) return fail(LDS_ENOMEM, "upload failed");
+    if (!f32 && (!make_split_twin(own, W1, fmt) || !make_split_twin(own, W2, fmt))) return fail(LDS_ENOMEM, "upload failed");
+    const int nT = (T + 31) / 32;
+    auto act = [&](int Cc) { return f32 ? (size_t)Cc * (T + 2) : split_floats(fmt, Cc, T); };
+    float* kx = tmp.f((size_t)B * act(C));
+    float* km = tmp.f((size_t)B * act(Cm));
+    float* ko = tmp.f((size_t)B * act(Co));
+    float* gp = tmp.f((size_t)B * (Cm / 16) * nT * 2);
+    float* kpart = tmp.f((size_t)kClusterPartFloats);
+    unsigned* kcount = (unsigned*)tmp.f(kClusterCounters);
+    if (!kx || !km || !ko || !gp || !kpart || !kcount) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(hipMemsetAsync(kcount, 0, sizeof(unsigned) * kClusterCounters, st));
+    HIP_TRY(to_act_any(f32 ? 0 : fmt + 1, x, kx, B, C, T, C, 0, st));
+    DOpt o1;
+    o1.gnpart_out = (float2*)gp;
+    LDS_TRY(dconv_any(f32 ? 0 : fmt + 1, W1, kx, C, nullptr, 0, T, o1, km, B, st));
+    if (f32) HIP_TRY(launch_from_k4p(km, mid, B, Cm, T, st));
+    else HIP_TRY(launch_from_k8b3(km, mid, B, Cm, T, st, fmt));
+    for (int rep = 0; rep < reps; ++rep) {
+        {
+            TileBatchScope tbs(tile_batch, kpart, kcount);
+            DOpt o2;
+            o2.cfg = cfg;
+            o2.gnf_part = (const float2*)gp; o2.gnf_groups = groups; o2.gnf_eps = eps; o2.gnf_cg = cg; o2.gnf_c2 = c2;
+            LDS_TRY(dconv_any(f32 ? 0 : fmt + 1, W2, km, Cm, nullptr, 0, T, o2, ko, B, st));
+        }
+        float* dst = out + (size_t)rep * B * Co * T;
+        if (f32) HIP_TRY(launch_from_k4p(ko, dst, B, Co, T, st));
+        else HIP_TRY(launch_from_k8b3(ko, dst, B, Co, T, st, fmt));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return LDS_OK;
 }

