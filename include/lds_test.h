@@ -55,6 +55,12 @@ int lds_test_gn_fold_k4p(const float* x, const float* w1, const float* bias1, co
 int lds_test_gn_fold_split(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps, int groups,
                            const float* w2, const float* bias2, float* mid, float* out, int B, int C, int Cm, int Co, int T, int cfg, int tile_batch,
                            int fmt, int reps, void* stream);
+/* the latency mode's cluster split-K hand-off (csrc/conv_dma.hip cluster_join): a K-tap (1 / 3) convolution Ci -> Co with the tile and cluster choices at
+ * tile_batch = B, launched `reps` times back to back alternating between the inputs xa / xb (a stale partial is then the other input's) into
+ * out[rep][B][Co][T]; ref_a / ref_b = the same tile shapes with one workgroup per tile; fmt -1 exact fp32, 0 / 1 split planes; cfg_out = the cluster
+ * launch's configuration ("... KS<S> ...": S workgroups per tile) */
+int lds_test_cluster_join(const float* xa, const float* xb, const float* w, const float* bias, int Ci, int Co, int K, int T, int B, int fmt, int reps,
+                          float* out, float* ref_a, float* ref_b, char* cfg_out, size_t cfg_cap, void* stream);
 /* mid = conv1x1(x) (+bias) written together with the epilogue's GroupNorm partial statistics; out = GroupNorm(mid)(+SiLU) by the
  * streaming pass that combines those partials -- the statistics path of the UNet (cfg: conv_dma tile code, 0 = auto) */
 int lds_test_gn_chain_k4p(const float* x, const float* w1, const float* bias1, const float* gamma, const float* beta, float eps,

@@ -628,7 +628,9 @@ struct Bf3Kernel {
         return true;
     }
 
-    // cluster split-K of the latency mode: as conv_dma.hip cluster_join (partials summed by the last wave to arrive, fixed order)
+    // cluster split-K of the latency mode: the hand-off of conv_dma.hip cluster_join, cell for cell (sc1 stores of every joining wave, their
+    // acknowledgement, a workgroup barrier, ONE lane's add on ONE counter per tile, the add that returns S - 1 came last, an LDS word behind a
+    // second barrier for the other waves, sc1 loads of the S partials in the fixed order s = 0 .. S-1)
     __device__ __forceinline__ bool cluster_join() {
         const int S = p.ksplit;
         const int slot = ctile * 4 + wave;
@@ -640,12 +642,15 @@ struct Bf3Kernel {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(p.kcount + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old != (unsigned)(S - 1)) return false;
-        if (lane == 0) __hip_atomic_store(p.kcount + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are acknowledged ...
+        __syncthreads();                                      // ... and so are those of every other (live) wave of the workgroup; the stages are free
+        int* last = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {                               // (wave 0 is a joining wave of every tile shape: split tiles keep waves 0 and 1)
+            const unsigned old = __hip_atomic_fetch_add(p.kcount + ctile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last = (old == (unsigned)(S - 1)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*last == 0) return false;
         const float* all = p.kpart + (long long)slot * S * (TM * TN * 1024) + lane;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -662,6 +667,7 @@ struct Bf3Kernel {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += __hip_atomic_load(pq + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (threadIdx.x == 0) __hip_atomic_store(p.kcount + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
 

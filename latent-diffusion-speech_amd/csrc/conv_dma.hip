@@ -698,12 +698,18 @@ struct DmaKernel {
         return true;
     }
 
-    // Cluster split-K (latency mode, DmaConvArgs::ksplit = S > 1): S workgroups share one output tile, each reducing 1/S of the K
-    // range.  Every wave writes its partial accumulators to kpart and counts itself in on its own counter; the wave that arrives
-    // last reads all S partials back in the fixed order s = 0 .. S-1 (its own included: the sum does not depend on the order of
-    // arrival) and runs the epilogue, the others leave.  No workgroup ever waits for another one.  Partials and counters travel
-    // as agent-scope accesses (sc1: write-through stores, L2-coherent loads), the counter add follows the wave's last store
-    // acknowledgement; the last wave puts the counter back to zero for the next launch.
+    // Cluster split-K (latency mode, DmaConvArgs::ksplit = S > 1): S workgroups share one output tile, each reducing 1/S of the K range.
+    // The hand-off follows ONE row of the hand-off table in MI355X_MICROARCH.md (inter-workgroup visibility, "ONE lane of each storing
+    // workgroup, for ALL that workgroup's stores ... all those lanes add to ONE unsharded counter, the workgroup whose add came last, told
+    // by the value its add returned"), in every cell:
+    //   * every wave stores its partial accumulators with sc1 (write-through) stores, 4 bytes each, and waits for their acknowledgement
+    //     (s_waitcnt vmcnt(0)); a workgroup barrier then makes that true of ALL the workgroup's stores;
+    //   * one lane of the workgroup adds 1 to the tile's counter (agent-scope atomic, one counter per tile); the add that returns S - 1 came last;
+    //   * that lane tells the workgroup's other waves through an LDS word behind a second barrier -- nobody loads a partial before it;
+    //   * the last workgroup's waves read all S partials back with sc1 loads (its own included) in the fixed order s = 0 .. S-1, so the sum does
+    //     not depend on the order of arrival, and run the epilogue; the others leave.  Nobody ever waits for another workgroup.
+    // One workgroup per CU (the launcher keeps a split grid within the chip), memory from hipMalloc.  The counter is put back to zero by the
+    // last workgroup after its loads are issued: the next reader of the counter is the next launch.
     __device__ __forceinline__ bool cluster_join() {
         const int S = p.ksplit;
         if constexpr (NACC == 2) {
@@ -725,12 +731,15 @@ struct DmaKernel {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[0][i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(p.kcount + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old != (unsigned)(S - 1)) return false;
-        if (lane == 0) __hip_atomic_store(p.kcount + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are acknowledged ...
+        __syncthreads();                                      // ... and so are those of every other (live) wave of the workgroup; the stages are free
+        int* last = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {                               // (wave 0 is a joining wave of every tile shape: split tiles keep waves 0 and 1)
+            const unsigned old = __hip_atomic_fetch_add(p.kcount + ctile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last = (old == (unsigned)(S - 1)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*last == 0) return false;
         const float* all = p.kpart + (long long)slot * S * (TM * TN * 1024) + lane;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -747,6 +756,7 @@ struct DmaKernel {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[0][i][j][r] += __hip_atomic_load(pq + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (threadIdx.x == 0) __hip_atomic_store(p.kcount + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
 

@@ -22,6 +22,9 @@ static __device__ __forceinline__ void chan(float& n, float& mean, float& m2, fl
 template <int CTRL, int ROW_MASK, bool BOUND>
 static __device__ __forceinline__ void chan_step(float& n, float& mean, float& m2) {
     // lanes outside ROW_MASK (and row starts with BOUND) receive zeros = an empty partial
+    // (the three values are complete, and two wait states have passed, before any lane reads them across the wave: the compiler may not weave
+    //  a step's arithmetic into the next step's cross-lane reads -- section 14 of DESIGN.md is about a schedule of this code that was not stable)
+    asm volatile("s_nop 1" : "+v"(n), "+v"(mean), "+v"(m2));
     const float nb = dpp_get<CTRL, ROW_MASK, BOUND>(n), mb = dpp_get<CTRL, ROW_MASK, BOUND>(mean), qb = dpp_get<CTRL, ROW_MASK, BOUND>(m2);
     chan(n, mean, m2, nb, mb, qb);
 }

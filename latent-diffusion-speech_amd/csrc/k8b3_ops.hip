@@ -115,6 +115,7 @@ static __device__ __forceinline__ void chan8(float& n, float& mean, float& m2, f
 }
 template <int CTRL, int ROW_MASK, bool BOUND>
 static __device__ __forceinline__ void chan_step8(float& n, float& mean, float& m2) {
+    asm volatile("s_nop 1" : "+v"(n), "+v"(mean), "+v"(m2));      // as gn_chan.h chan_step: complete values, then the cross-lane reads
     const float nb = dpp_get8<CTRL, ROW_MASK, BOUND>(n), mb = dpp_get8<CTRL, ROW_MASK, BOUND>(mean), qb = dpp_get8<CTRL, ROW_MASK, BOUND>(m2);
     chan8(n, mean, m2, nb, mb, qb);
 }

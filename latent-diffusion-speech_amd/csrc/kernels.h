@@ -117,8 +117,8 @@ struct DmaConvArgs {
     // of the scattered tensor in polyphase mode), written as zeros beyond; null = none
     const int* vlen;
     // Cluster split-K (latency mode only; conv_dma.hip cluster_join): ksplit = S > 1 workgroups share an output tile, each reducing 1/S
-    // of the K-steps; kpart = scratch for the partial tiles (tiles x 4 waves x S x 1024 floats), kcount = one zeroed counter per
-    // (tile, wave), left zeroed.  The launchers choose S (conv_dma_cluster_split) when tile_batch > 0 and kpart / kcount are given.
+    // of the K-steps; kpart = scratch for the partial tiles (tiles x 4 waves x S x 1024 floats), kcount = one zeroed counter per tile,
+    // left zeroed.  The launchers choose S (conv_dma_cluster_split) when tile_batch > 0 and kpart / kcount are given.
     int ksplit;
     float* kpart; unsigned* kcount;
     long long kpart_cap; int kcount_cap;      // capacities (floats / counters)

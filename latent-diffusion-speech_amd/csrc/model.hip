@@ -2345,6 +2345,53 @@ extern "C" int lds_test_gn_fold_split(const float* x, const float* w1, const flo
     return LDS_OK;
 }
 
+// The cluster split-K hand-off under test (conv_dma.hip / conv_bf3.hip cluster_join): a K-tap convolution Ci -> Co over [B, Ci, T] with the latency
+// mode's tile and cluster choices at tile_batch = B, launched `reps` times back to back ALTERNATING between the inputs xa and xb -- the partial
+// tiles of consecutive launches share their scratch slots, so a partial read stale (from this CU's L1, from the XCD's L2) is the other input's and
+// shows as an O(1) error -- into out[rep][B][Co][T]; ref_a / ref_b: the same tile shapes with one workgroup per tile (no cluster).  fmt -1 = exact
+// fp32 (conv_dma), 0 / 1 = split planes (conv_bf3).  cfg_out: the cluster launch's configuration string ("... KS<S> ...").
+extern "C" int lds_test_cluster_join(const float* xa, const float* xb, const float* w, const float* bias, int Ci, int Co, int K, int T, int B, int fmt, int reps,
+                                     float* out, float* ref_a, float* ref_b, char* cfg_out, size_t cfg_cap, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!xa || !xb || !w || !out || !ref_a || !ref_b || reps < 1 || (K != 1 && K != 3) || (fmt != -1 && fmt != FMT_BF16X3 && fmt != FMT_F16X2)) return fail(LDS_EINVAL, "bad argument");
+    const bool f32 = fmt < 0;
+    const int mode = f32 ? 0 : fmt + 1;
+    Owner own;
+    TmpDev tmp;
+    ConvW W;
+    if (!pack_conv(own, w, bias, Co, Ci, K, W) || (!f32 && !make_split_twin(own, W, fmt))) return fail(LDS_ENOMEM, "upload failed");
+    auto act = [&](int Cc) { return f32 ? (size_t)Cc * (T + 2) : split_floats(fmt, Cc, T); };
+    float* ka = tmp.f((size_t)B * act(Ci));
+    float* kb = tmp.f((size_t)B * act(Ci));
+    float* ko = tmp.f((size_t)B * act(Co));
+    float* kpart = tmp.f((size_t)kClusterPartFloats);
+    unsigned* kcount = (unsigned*)tmp.f(kClusterCounters);
+    if (!ka || !kb || !ko || !kpart || !kcount) return fail(LDS_ENOMEM, "alloc");
+    HIP_TRY(hipMemsetAsync(kcount, 0, sizeof(unsigned) * kClusterCounters, st));
+    HIP_TRY(to_act_any(mode, xa, ka, B, Ci, T, Ci, 0, st));
+    HIP_TRY(to_act_any(mode, xb, kb, B, Ci, T, Ci, 0, st));
+    DOpt o;
+    o.pad = K / 2;
+    auto back = [&](float* dst) { return f32 ? launch_from_k4p(ko, dst, B, Co, T, st) : launch_from_k8b3(ko, dst, B, Co, T, st, fmt); };
+    {
+        TileBatchScope tbs(B, nullptr, nullptr);      // the same tile choices, no scratch: one workgroup per tile
+        LDS_TRY(dconv_any(mode, W, ka, Ci, nullptr, 0, T, o, ko, B, st));
+        HIP_TRY(back(ref_a));
+        LDS_TRY(dconv_any(mode, W, kb, Ci, nullptr, 0, T, o, ko, B, st));
+        HIP_TRY(back(ref_b));
+    }
+    for (int rep = 0; rep < reps; ++rep) {
+        {
+            TileBatchScope tbs(B, kpart, kcount);
+            LDS_TRY(dconv_any(mode, W, (rep & 1) ? kb : ka, Ci, nullptr, 0, T, o, ko, B, st));
+        }
+        if (rep == 0 && cfg_out && cfg_cap) snprintf(cfg_out, cfg_cap, "%s", f32 ? conv_dma_last_config() : conv_bf3_last_config());
+        HIP_TRY(back(out + (size_t)rep * B * Co * T));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
+
 extern "C" int lds_test_ln_chain_k4p(const float* x, const float* w1, const float* w2, const float* gamma, const float* beta, float eps,
                                      float* mid, float* out, int B, int C, int Co, int T, void* stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -53,6 +53,66 @@ def test_gn_fold_repeatable_and_right(fmt, Cm, T, B, tile_batch, record_margin):
     record_margin(relmax(out[0].cpu().numpy(), ref), 2e-5)
 
 
+# (Ci, Co, K, T, B): the latency mode's deep reductions -- T/8 and T/4 level shapes of one and two 512-frame utterances (S = 16 .. 2), a k 3
+# resnet convolution, the 2560-deep ff.net.2 + proj_out
+CLUSTER = [(512, 512, 1, 64, 1), (512, 512, 3, 64, 1), (2560, 512, 1, 64, 1), (512, 512, 1, 128, 2), (384, 384, 3, 256, 1), (1024, 512, 3, 64, 2), (256, 256, 1, 512, 1)]
+
+
+@pytest.mark.parametrize("Ci,Co,K,T,B", CLUSTER)
+@pytest.mark.parametrize("fmt", ["f32", "split_f16", "split_bf16"])
+def test_cluster_join_under_uneven_load(fmt, Ci, Co, K, T, B):
+    """the cluster split-K hand-off the way MI355X_MICROARCH.md asks for hand-offs to be tested: the chip unevenly loaded (a second stream streams
+    HBM meanwhile), the consumer L1-warm (back-to-back launches reuse the same scratch slots, alternating between two inputs so that a stale
+    partial is the OTHER input's), every word of every joined tile compared -- with the one-workgroup-per-tile result of the same tile shape, and bit
+    for bit with the first launch on the same input"""
+    from lds import init_weights, native
+    U = lambda n, s, lo=-1.0, hi=1.0: init_weights.uniform(f"cj.{Ci}.{K}.{T}.{n}", s, 9, lo, hi)
+    reps = 60
+    xa, xb = U("xa", (B, Ci, T), -2, 2), U("xb", (B, Ci, T), -2, 2)
+    w = (U("w", (Co, Ci, K)) / np.float32(np.sqrt(Ci * K))).astype(np.float32)
+    bias = U("b", (Co,), -0.5, 0.5)
+    da, db = torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda()
+    out = torch.full((reps, B, Co, T), float("nan"), dtype=torch.float32, device="cuda")
+    ra, rb = torch.empty((B, Co, T), dtype=torch.float32, device="cuda"), torch.empty((B, Co, T), dtype=torch.float32, device="cuda")
+    big = torch.zeros(256 << 20, dtype=torch.float32, device="cuda")      # 1 GiB, streamed on a second stream by a second host thread while the launches run
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    import threading
+    stop, passes = threading.Event(), [0]
+
+    def load():
+        with torch.cuda.stream(side):
+            while not stop.is_set() and passes[0] < 20000:
+                for _ in range(4):
+                    big.add_(1.0)
+                side.synchronize()      # (bounds the queue: at most four passes, ~2 ms, are ever pending)
+                passes[0] += 4
+
+    th = threading.Thread(target=load)
+    th.start()
+    while passes[0] < 8:      # the load is running before the entry point starts
+        pass
+    before = passes[0]
+    cfg = ct.create_string_buffer(128)
+    P = lambda v: ct.c_void_p(v.ctypes.data)
+    try:
+        native.check(native.lib().lds_test_cluster_join(ct.c_void_p(da.data_ptr()), ct.c_void_p(db.data_ptr()), P(w), P(bias), Ci, Co, K, T, B, FMT[fmt], reps,
+                                                        ct.c_void_p(out.data_ptr()), ct.c_void_p(ra.data_ptr()), ct.c_void_p(rb.data_ptr()), cfg, ct.c_size_t(len(cfg)),
+                                                        ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    finally:
+        during = passes[0] - before
+        stop.set()
+        th.join()
+    torch.cuda.synchronize()
+    assert " KS" in cfg.value.decode(), f"no cluster split was chosen: {cfg.value.decode()}"
+    assert during >= 4, "the second stream did not stream while the launches under test ran"
+    refs = (ra.cpu().numpy(), rb.cpu().numpy())
+    o = out.cpu().numpy()
+    for r in range(reps):
+        assert relmax(o[r], refs[r & 1]) < 2e-5, (r, cfg.value.decode(), relmax(o[r], refs[r & 1]))
+        assert np.array_equal(o[r], o[r & 1]), f"launch {r} differs from launch {r & 1} on the same input ({cfg.value.decode()})"
+
+
 PATTERNS = {"zeros": 0x00000000, "nan": 0x7FC07FC0, "ones": 0x3F803C00, "big": 0x7B007B00}
 
 
@@ -86,6 +146,21 @@ def test_unet_poisoned_workspace(unet_any, mode, latency, B, T):
     finally:
         unet.set_latency_mode(False)
         unet.set_gemm_mode("f32")
+
+
+def test_unet_poisoned_workspace_bench_size(unet_any):
+    """the bench's own shape (16 utterances x 512 frames, exact fp32, default mode): every CU holds several workgroups of every launch"""
+    from lds import init_weights, native
+    unet = unet_any
+    B, T = 16, 512
+    x = torch.from_numpy(init_weights.uniform("poison.bench", (B, 336, T), 34, -2, 2)).cuda()
+    t = torch.from_numpy(np.linspace(3.5, 990.25, B).astype(np.float32)).cuda()
+    outs = []
+    for pat in (0, 0x7FC07FC0, 0x3F803C00, 0):
+        native.debug_fill(unet.native().workspace_tensor(B, T, x.device), pat)
+        outs.append(unet(x, t).sample.clone())
+    assert all(torch.isfinite(o).all() for o in outs)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
 
 
 @pytest.mark.parametrize("method,speedup", [("dpm-solver", 250), ("unipc", 250)])
