@@ -17,9 +17,9 @@ never silently measure one GPU.  --workload: sampler (configs[1] / [2]: the head
 + HiFi-VAEGAN decode, waveform gathered), full_tts (configs[4]: phones -> RoFormer generate -> codebook ->
 sampler -> vocoder, 8 utterances per GPU).  At N = 1 the sampler line also carries `extra` legs (untimed
 for `value`): configs[3] with the vocoder, the per-GPU share of configs[2] (UniPC, 20 NFE), the B = 1
-latency of the caller north_star names (22_infer_tts.py), and `split_bf16`: the same configs[1] step with
-every UNet GEMM on the fp32-equivalent split-bf16 path (csrc/conv_bf3.hip), reported next to -- never as --
-the exact-fp32 `value`.
+latency of the caller north_star names (22_infer_tts.py), and `split_f16`: the same configs[1] step with
+every UNet GEMM on the opt-in two-fp16-term path (csrc/conv_bf3.hip; 22-bit operands, narrower than the
+reference's fp32), reported next to -- never as -- the exact-fp32 `value`.
 """
 import argparse
 import json
@@ -36,11 +36,8 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (same table); the split-bf16 path spends 6 bf16 products per fp32 product
-PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_SPLIT_F16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0   # fp16 MFMA = the bf16 rate; the fp16-pair path spends 3 products per fp32 product
-SPLIT_MODES = {
-    "split_bf16": {"dtype": "f32-equivalent (3xbf16 operands, 6 products, f32 accumulate)", "peak": PEAK_SPLIT_BF16_TFLOPS,
-                   "peak_note": "2.5 PFLOP/s dense bf16 / 6 bf16 products per fp32 product"},
+SPLIT_MODES = {      # (the lossless three-bf16 mode of round 3 was removed: it ran no faster than exact fp32)
     "split_f16": {"dtype": "2xfp16 operands (22 significand bits, weights pre-scaled per layer), 3 products, f32 accumulate", "peak": PEAK_SPLIT_F16_TFLOPS,
                   "peak_note": "2.5 PFLOP/s dense fp16 / 3 fp16 products per fp32 product"},
 }
@@ -350,8 +347,8 @@ def run_job(args, rank, world, dev, model=None, voc=None, dist=None, sync=None, 
 
 def split_leg(args, model, make_inputs, mode):
     """configs[1] again with every convolution / linear layer of the UNet as a split-operand GEMM on the 16-bit matrix pipe
-    (csrc/conv_bf3.hip, csrc/k8b3.h).  mode "split_bf16": three bf16 terms per fp32 operand (lossless), six products; "split_f16": two fp16
-    terms (22 bits; per-layer weight scale), three products; fp32 accumulate in both.  Same parity suite, same tolerances
+    (csrc/conv_bf3.hip, csrc/k8b3.h).  mode "split_f16": two fp16 terms per fp32 operand (22 bits; per-layer weight scale), three products,
+    fp32 accumulate.  Same parity suite, same tolerances
     (tests/test_gpu_model.py runs every whole-path test in all modes); error study: profiles/r03_split_probe_bf16x3_f16x2.json.  Reported
     next to the exact-fp32 `value`, never as it."""
     info = SPLIT_MODES[mode]
@@ -360,18 +357,13 @@ def split_leg(args, model, make_inputs, mode):
     sync = torch.cuda.synchronize
     keep = {}
 
-    def step():
-        keep["mel"] = model(units, None, spk_id=spk, infer=True, infer_speedup=1000 // args.nfe, method=args.method)
+    def step(x_T=None):
+        keep["mel"] = model(units, None, spk_id=spk, infer=True, infer_speedup=1000 // args.nfe, method=args.method, x_T=x_T)
 
-    def seeded(mode):                                           # one run with an injected x_T, so the two paths see the same start
+    def seeded(mode):                                           # one run with a given x_T, so the two paths see the same start
         unet.set_gemm_mode(mode)
-        real = torch.randn
-        xT = real((args.batch, 1, 80, args.frames), device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
-        torch.randn = lambda *a, **k: xT.clone()
-        try:
-            step(); sync()
-        finally:
-            torch.randn = real
+        xT = torch.randn((args.batch, 1, 80, args.frames), device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+        step(xT); sync()
         return keep["mel"].clone()
     try:
         y32, y16 = seeded("f32"), seeded(mode)
@@ -555,14 +547,15 @@ def extra_legs(args, dev, model, make_inputs):
             unet.set_latency_mode(False)
     assert all(bool(torch.isfinite(w_).all()) for _, w_ in keep["rag"])
 
-    def ragged_masked():      # ONE padded sampler batch with per-utterance lengths in the kernels, vocoder by bucket on 4 streams
+    def ragged_masked():      # ONE padded batch with per-utterance lengths inside the kernels: the sampler AND the vocoder (lds_*_ragged)
         keep["ragm"] = infer_tts.synthesize_ragged_masked(svc, codebook, rag_rows, 1, 1000 // args.nfe, args.method, streams=4, max_batch=16)
     rag["masked_batch_ms"] = 1e3 * timeit(ragged_masked, 1)
     assert all(bool(torch.isfinite(w_).all()) for _, w_ in keep["ragm"])
     extra["ragged16_tokens_to_wav"] = {
         "workload": f"{len(rag_rows)} utterances of {len(rag_rows)} different lengths (272 .. 512 frames, {rag_frames} in all): units -> {args.nfe}-step {args.method} "
                     "-> HiFi-VAEGAN, one bucket per length (bit-identical with each utterance alone); streams4 = buckets overlapped on 4 HIP streams / host threads; "
-                    "masked_batch = the sampler as ONE padded batch with per-utterance lengths inside the kernels (lds_sampler_run_ragged; parity tolerance, not bit-identity)",
+                    "masked_batch = sampler and vocoder each as ONE padded batch with per-utterance lengths inside the kernels (lds_sampler_run_ragged, "
+                    "lds_vocoder_forward_ragged; parity tolerance, not bit-identity)",
         **rag, "best_x_realtime": rag_frames * FRAME_SEC / (min(rag.values()) * 1e-3),
     }
     # ---- the 22_infer_tts.py caller itself: ONE utterance, phones -> tokens -> units -> mel -> wav ----
@@ -659,9 +652,18 @@ class _StubUnit2Mel:
         return 2.0 * units[..., :80] + spk_id.to(torch.float32)[:, :, None]
 
 
-def build_pipeline(args, dev):
-    """models + the pipeline object of --workload (seeded random-init weights: no checkpoints exist)"""
-    from lds import init_weights
+def build_pipeline(args, dev, rank=0, world=1, dist=None):
+    """models + the pipeline object of --workload (seeded random-init weights: no checkpoints exist).  Multi-rank: rank 0
+    generates the weights, every other rank builds its modules empty and receives them by ONE broadcast per model (lds/shard.py broadcast_state:
+    RCCL on the GPU, north_star's "RCCL broadcast/gather"); every rank then packs its own copy for its own device."""
+    import contextlib
+    from lds import init_weights, shard
+    force = dist is not None and world == 1      # --rehearse-rccl: the broadcast runs on a single-rank group too
+    share = (world > 1 or force) and not args.stub_cpu
+    empty = (lambda: init_weights.deferred()) if (share and rank != 0) else contextlib.nullcontext
+
+    def bcast(state):
+        return shard.broadcast_state(state, rank, world, device=dev, force=force) if share else 0
 
     def make_inputs(n, T):
         units = torch.from_numpy(init_weights.uniform("bench.units", (n, T, 1280), 1, -1.7, 1.7))
@@ -678,19 +680,34 @@ def build_pipeline(args, dev):
         return model, make_inputs, SamplerPipeline(args, model, make_inputs, voc)
 
     from diffusion.unit2mel import Unit2Mel
-    model = Unit2Mel(1280, 323, 80).to(dev).eval()           # build-owned seeded init, seed 0
+    with empty():
+        model = Unit2Mel(1280, 323, 80).to(dev).eval()       # build-owned seeded init, seed 0 (rank 0; the others receive it)
+    moved = bcast(model.state_dict())
     voc = None
     if args.workload != "sampler":
         from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
         from lds import arch
         h = arch.SYNTHETIC_VOCODER_H
-        voc = Hifi_VAEGAN(None, device=dev, h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
+        with empty():
+            vstate = {k: torch.from_numpy(v).to(dev) for k, v in init_weights.init_state(arch.generator_param_shapes(h), 0).items()}
+        moved += bcast(vstate)
+        voc = Hifi_VAEGAN(None, device=dev, h=h, state={k: v.cpu().numpy() for k, v in vstate.items()})
     if args.workload == "full_tts":
         sys.path.insert(0, ROOT)
         import infer_tts
         from lds import native
-        lm = infer_tts.synthetic_lm(dev)
-        codebook = torch.from_numpy(init_weights.uniform("synthetic.codebook", (4096, 1280), 5, -1.7, 1.7)).to(dev)
+        with empty():
+            lm = infer_tts.synthetic_lm(dev)
+        if share and rank != 0:
+            codebook = torch.zeros(4096, 1280, device=dev)
+        else:
+            codebook = torch.from_numpy(init_weights.uniform("synthetic.codebook", (4096, 1280), 5, -1.7, 1.7)).to(dev)
+        moved += bcast(lm.state_dict()) + bcast({"codebook": codebook})
+    args.weights_broadcast_bytes = moved
+    if not args.stub_cpu:      # pack this rank's copy now (host work + upload): part of set-up, not of the first timed step
+        model.decoder.denoise_fn.native()
+        model._native_embed()
+    if args.workload == "full_tts":
 
         def t2s(phones, tones, max_length):
             torch.manual_seed(1234)                           # the top-k sampler's uniforms: the same draws every step
@@ -734,10 +751,21 @@ def main(argv=None):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    model, make_inputs, pipe = build_pipeline(args, dev)
+    t_setup = time.perf_counter()
+    model, make_inputs, pipe = build_pipeline(args, dev, rank, world, dist)
+    if sync is not None:
+        sync()
+    setup_s = time.perf_counter() - t_setup
+    if dist is not None:      # the slowest rank's set-up is what the job waits for
+        smax = torch.tensor([setup_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+        setup_s = float(smax.item())
     profiler = None if (args.no_profile or args.stub_cpu) else NativeProfiler()
     res = run_job(args, rank, world, dev, dist=dist, sync=sync, profiler=profiler, pipeline=pipe)
     if rank == 0:
+        # set-up per rank (max over ranks): weights generated on rank 0 and broadcast, packed on every rank, uploaded; not part of `value`
+        res["setup_s"] = setup_s
+        res["weights_broadcast_bytes"] = getattr(args, "weights_broadcast_bytes", 0)
         if world == 1 and not args.no_extras and not args.stub_cpu and args.workload == "sampler":
             res["extra"] = extra_legs(args, dev, model, make_inputs)
         if not args.no_cpu_baseline and world == 1 and not args.stub_cpu:      # reported on rank 0 at N = 1 only

@@ -200,16 +200,21 @@ int lds_lm_generate(lds_lm* lm, const float* enc, const int32_t* enc_len, int B,
 int lds_prof_enable(int on);
 int lds_prof_summary(char* buf, size_t cap);
 
-/* ---- exact-fp32 vs fp32-equivalent split-bf16 GEMMs (csrc/conv_bf3.hip, csrc/k8b3.h) ------------------------------------
- * mode 0 (default): every convolution / linear layer of the UNet on the exact-fp32 MFMA (a k-ordered fmaf chain).
- * mode 1: the same layers on the bf16 MFMA with every fp32 operand held as three bf16 terms (lossless) and six bf16 products per
- * fp32 product, fp32 accumulate: same tolerances against the reference (tests/test_gpu_bf3.py, profiles/r03_split_bf16_probe.json).
- * The first switch to mode 1 packs the split weights (host work + upload); later switches only flip the flag.  Not thread-safe
- * against concurrent forwards on the same handle. */
+/* ---- exact-fp32 vs split-operand GEMMs on the 16-bit matrix pipe (csrc/conv_bf3.hip, csrc/k8b3.h) ------------------------------------
+ * mode 0 (default, what bench.py's `value` is measured in): every convolution / linear layer of the UNet on the exact-fp32 MFMA (a k-ordered
+ * fmaf chain).
+ * mode 1 (three bf16 terms per operand, lossless, six products) was a whole-UNet mode in round 3 and is REMOVED: it met the tolerances and ran no
+ * faster than mode 0; lds_unet_set_gemm_mode(1) returns LDS_EINVAL.  The kernel format survives for the single-op probes
+ * (include/lds_test.h lds_test_dconv_split, tools/split_bf16_probe.py).
+ * mode 2 (opt-in, experimental, never a default): two fp16 terms per operand -- 22 significand bits, NARROWER than the reference's fp32 -- three
+ * products, fp32 accumulate; weights carry a per-layer power-of-two scale.  PRECONDITION on the activations: every tensor between kernels must
+ * stay below 65,504 in magnitude (an overflow becomes an infinity, then a NaN: loud) and should live at a scale of 2^-3 or more: below that
+ * the second fp16 term is subnormal and the tensor keeps fewer than 22 bits (down to 11 at 6e-5), silently.  Attention probabilities are
+ * exempt (formed times 2^12 inside the kernel).  UNet1DConditionModel.check_split_f16_ranges (Python) reports every tensor's range for given
+ * inputs and raises outside [2^-3, 2^15].  The first switch packs the split weights (host work + upload); later switches only flip the flag.
+ * Switching modes is not thread-safe against concurrent forwards on the same handle (one mode per handle lifetime is the supported use). */
 #define LDS_GEMM_F32 0
-#define LDS_GEMM_SPLIT_BF16 1
-/* mode 2 (experimental): two fp16 terms per operand (22 significand bits, 4 bytes per element), three products; weights carry a per-layer
- * power-of-two scale, activations must stay below 65504 in magnitude (csrc/k8b3.h).  Same test suite; error study in profiles/. */
+#define LDS_GEMM_SPLIT_BF16 1      /* removed: LDS_EINVAL */
 #define LDS_GEMM_SPLIT_F16 2
 int lds_unet_set_gemm_mode(lds_unet* u, int mode);
 int lds_unet_get_gemm_mode(const lds_unet* u);

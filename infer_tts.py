@@ -35,7 +35,7 @@ def parse_args(argv=None):
                     help="nearest-resample the unit frames by this factor first (22_infer_tts.py:108-110, units_forced_alignment)")
     ap.add_argument("--latency_mode", action="store_true",
                     help="one sentence per call: tile shapes / reduction splits from the actual batch (include/lds.h lds_unet_set_latency_mode)")
-    ap.add_argument("--gemm_mode", default="f32", choices=["f32", "split_bf16", "split_f16"], help="the UNet's GEMMs (include/lds.h lds_unet_set_gemm_mode)")
+    ap.add_argument("--gemm_mode", default="f32", choices=["f32", "split_f16"], help="the UNet's GEMMs (include/lds.h lds_unet_set_gemm_mode)")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--synthetic_tokens", type=int, default=256)
     return ap.parse_args(argv)
@@ -92,9 +92,14 @@ def text2semantic(lm, phones, tones, spk_id=1, max_length=1024):
     spk = torch.ones_like(phones) * spk_id
     tok = lm.generate(phones, tones, attention_mask=None, use_cache=None, max_length=max_length, do_sample=True, temperature=1.0, top_k=5, top_p=1.0,
                       repetition_penalty=1.0, num_beams=1, no_repeat_ngram_size=0, early_stopping=True, spk_id=spk, end_gate_threshold=None)
-    if tok.shape[0] == 1 and int(tok[0, -1]) == lm.semantic_eos_token_id:      # the reference's check is written for one utterance
+    # reference 22_infer_tts.py:100-103 (`if semantic_token[:, -1] == eos`: written for one utterance; on a batch that line itself raises).
+    # The batched counterpart: every row ending with its EOS at the same step is stripped like the single row; rows that all ran to max_length
+    # come back whole; rows that ended at DIFFERENT steps (EOS / PAD ids inside the result) cannot be one rectangular tensor.
+    eos = lm.semantic_eos_token_id
+    body_has_stop = bool((tok[:, 1:-1] >= eos).any()) if tok.shape[1] > 2 else False
+    if not body_has_stop and bool((tok[:, -1] == eos).all()):
         return tok[:, 1:-1]
-    if tok.shape[0] > 1 and bool((tok[:, 1:] >= lm.semantic_eos_token_id).any()):
+    if body_has_stop or bool((tok[:, -1] >= eos).any()):
         raise ValueError("rows of a batch ended at different lengths (EOS / PAD ids in the result): use text2semantic_rows, which cuts every "
                          "row at its own EOS, and synthesize_ragged")
     return tok[:, 1:]
@@ -153,16 +158,12 @@ def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, me
         for j, i in enumerate(idx):
             tok[j, :lens[j]] = token_rows[i]
         units = native.gather_rows(codebook, tok)
-        real = torch.randn
-        if noise_fn is not None:
+        xT = None
+        if noise_fn is not None:      # the start noise handed down explicitly (GaussianDiffusion.forward's x_T), every row at its own length
             xT = torch.zeros(len(idx), 1, svc.model.decoder.out_dims, T, device=codebook.device)
             for j, i in enumerate(idx):
                 xT[j:j + 1, :, :, :lens[j]] = noise_fn([i], lens[j])
-            torch.randn = lambda *a, **k: xT.clone()
-        try:
-            mel = svc.call_ragged(units, lens, spk_id=spk_id, infer_speedup=speedup, method=method)
-        finally:
-            torch.randn = real
+        mel = svc.call_ragged(units, lens, spk_id=spk_id, infer_speedup=speedup, method=method, x_T=xT)
         if ragged_vocoder:      # ... and the vocoder on the same padded batch, every stage masked at the utterance's up-sampled length
             wav = svc.vocoder.infer_ragged(mel, lens)
             hop = wav.shape[-1] // T
@@ -171,7 +172,7 @@ def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, me
         for j, i in enumerate(idx):
             mels[i] = mel[j, :lens[j]].contiguous()
     if ragged_vocoder:
-        return [(mels[i], wavs[i]) if token_rows[i].numel() else (torch.empty(0, codebook.shape[1]), torch.empty(0)) for i in range(len(token_rows))]
+        return [(mels[i], wavs[i]) if token_rows[i].numel() else (torch.empty(0, svc.model.decoder.out_dims), torch.empty(0)) for i in range(len(token_rows))]
     # ragged_vocoder = False: the vocoder per length bucket (bit-identical with each mel decoded alone)
     out = [None] * len(token_rows)
     by_len = {}
@@ -181,7 +182,7 @@ def synthesize_ragged_masked(svc, codebook, token_rows, spk_id=1, speedup=10, me
     def voc_bucket(T, idx):
         if T == 0:
             for i in idx:
-                out[i] = (torch.empty(0, codebook.shape[1]), torch.empty(0))
+                out[i] = (torch.empty(0, svc.model.decoder.out_dims), torch.empty(0))
             return
         wav = svc.mel2wav(torch.stack([mels[i] for i in idx]), None)
         for j, i in enumerate(idx):
@@ -225,18 +226,12 @@ def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="d
     def run_bucket(T, idx):
         if T == 0:
             for i in idx:
-                out[i] = (torch.empty(0, codebook.shape[1]), torch.empty(0))
+                out[i] = (torch.empty(0, svc.model.decoder.out_dims), torch.empty(0))
             return
         tok = torch.stack([token_rows[i] for i in idx])
         units = native.gather_rows(codebook, tok)
-        real = torch.randn
-        if noise_fn is not None:
-            xT = noise_fn(idx, T)
-            torch.randn = lambda *a, **k: xT.clone()
-        try:
-            mel = svc(units, f0=None, volume=None, spk_id=spk_id, infer_speedup=speedup, method=method)
-        finally:
-            torch.randn = real
+        xT = noise_fn(idx, T) if noise_fn is not None else None
+        mel = svc(units, f0=None, volume=None, spk_id=spk_id, infer_speedup=speedup, method=method, x_T=xT)
         wav = svc.mel2wav(mel, None)
         for j, i in enumerate(idx):
             out[i] = (mel[j], wav[j, 0])
@@ -260,16 +255,12 @@ def synthesize_ragged(svc, codebook, token_rows, spk_id=1, speedup=10, method="d
         with torch.cuda.stream(pool[k]):
             for T, idx in buckets[k::len(pool)]:
                 run_bucket(T, idx)
-    if noise_fn is not None:      # the injected noise swaps torch.randn, a process-wide name: one host thread, several streams
-        for k in range(len(pool)):
-            worker(k)
-    else:
-        import threading
-        ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(pool))]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+    import threading
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(pool))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
     for s_ in pool:
         cur.wait_stream(s_)
     for mel_wav in out:      # the caller's stream owns the results from here on

@@ -231,7 +231,11 @@ __global__ void __launch_bounds__(NW * 64) attention_k4p_kernel(const float* __r
             // more in register copies at the join than the 8 packed multiplies it saves)
             const float alpha = __builtin_amdgcn_exp2f(m_run - mt);
             m_run = mt;
-            const f32x2 mm = {mt, mt}, aa = {alpha, alpha};
+            // F16: the probabilities are formed times 2^12 (the exponent rides in the exp2 argument: no extra instruction).  Their fp16 split then
+            // keeps 22 bits down to p = 2^-26 instead of 2^-14 -- over 2050 keys a typical p is 5e-4, whose second fp16 term would be subnormal --
+            // and the factor cancels exactly in o / l (both sums carry it; partial sums of different waves / tiles carry the same one).
+            const float msub = F16 ? mt - 12.0f : mt;
+            const f32x2 mm = {msub, msub}, aa = {alpha, alpha};
             f32x2 lsum = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {

@@ -1059,7 +1059,9 @@ static bool unet_pack_split(lds_unet* u, int fmt) {
     return ok;
 }
 extern "C" int lds_unet_set_gemm_mode(lds_unet* u, int mode) {
-    if (!u || (mode != LDS_GEMM_F32 && mode != LDS_GEMM_SPLIT_BF16 && mode != LDS_GEMM_SPLIT_F16)) return fail(LDS_EINVAL, "bad argument");
+    if (u && mode == LDS_GEMM_SPLIT_BF16)
+        return fail(LDS_EINVAL, "the split-bf16 UNet mode was removed in round 4: lossless but no faster than exact fp32 (DESIGN 10.1); the kernel format remains (lds_test_dconv_split)");
+    if (!u || (mode != LDS_GEMM_F32 && mode != LDS_GEMM_SPLIT_F16)) return fail(LDS_EINVAL, "bad argument");
     if (mode != LDS_GEMM_F32 && !u->split_packed[mode - 1]) {
         if (u->M % 16 || u->H % 16) return fail(LDS_EINVAL, "split GEMM modes need out_dims and n_hidden to be multiples of 16");
         if (!unet_pack_split(u, mode - 1)) return fail(LDS_ENOMEM, "packing the split weights failed");

@@ -245,16 +245,18 @@ class GaussianDiffusion(nn.Module):
         return native.axpby(x_start.contiguous(), noise.contiguous(), float(self._buf("sqrt_alphas_cumprod")[ti]),
                             float(self._buf("sqrt_one_minus_alphas_cumprod")[ti]))
 
-    def forward(self, condition, gt_spec=None, infer=True, infer_speedup=10, method="dpm-solver", k_step=None, use_tqdm=False):
-        return self._sample(condition, gt_spec, infer, infer_speedup, method, k_step, None)
+    def forward(self, condition, gt_spec=None, infer=True, infer_speedup=10, method="dpm-solver", k_step=None, use_tqdm=False, *, x_T=None):
+        """reference diffusion.py:189 plus one optional keyword: x_T [B,1,M,T] = the start noise to use instead of drawing it (tests, seeded
+        runs; the reference draws torch.randn itself, diffusion.py:201).  The samplers' other draws (DDPM: one per step) stay torch.randn."""
+        return self._sample(condition, gt_spec, infer, infer_speedup, method, k_step, None, x_T)
 
-    def forward_ragged(self, condition, lengths, gt_spec=None, infer_speedup=10, method="dpm-solver", k_step=None):
+    def forward_ragged(self, condition, lengths, gt_spec=None, infer_speedup=10, method="dpm-solver", k_step=None, x_T=None):
         """Extension (not in the reference): a RAGGED batch in one call.  condition [B, T, H] padded to the longest utterance, lengths [B] the
         utterances' own frame counts; every utterance is sampled as if it ran alone at its own length (include/lds.h lds_sampler_run_ragged);
         frames of the result beyond an utterance's length are zeros."""
-        return self._sample(condition, gt_spec, True, infer_speedup, method, k_step, lengths)
+        return self._sample(condition, gt_spec, True, infer_speedup, method, k_step, lengths, x_T)
 
-    def _sample(self, condition, gt_spec, infer, infer_speedup, method, k_step, lengths):
+    def _sample(self, condition, gt_spec, infer, infer_speedup, method, k_step, lengths, x_T=None):
         if not infer:
             raise NotImplementedError("training (p_losses) is out of scope for the MI355X sampler build")
         if not condition.is_cuda:
@@ -264,9 +266,16 @@ class GaussianDiffusion(nn.Module):
         shape = (cond.shape[0], 1, self.out_dims, cond.shape[2])
         if gt_spec is None or k_step is None:
             t = self.k_step
-            x = torch.randn(shape, device=device)
+            if x_T is None:
+                x = torch.randn(shape, device=device)
+            else:
+                if tuple(x_T.shape) != shape or x_T.device != device:
+                    raise ValueError(f"x_T must be a {shape} tensor on {device}, got {tuple(x_T.shape)} on {x_T.device}")
+                x = x_T.float().clone()      # (the sampler updates its state in place)
         else:
             t = k_step
+            if x_T is not None:
+                raise ValueError("x_T applies to a full run; the shallow entry starts from q_sample(gt_spec)")
             norm_spec = native.transpose(self.norm_spec(gt_spec).contiguous().float())[:, None, :, :]
             x = self.q_sample(x_start=norm_spec, t=torch.tensor([t - 1], device=device).long())
         x = x.reshape(b, self.out_dims, -1).contiguous()

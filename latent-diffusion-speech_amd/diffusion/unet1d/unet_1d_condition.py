@@ -69,13 +69,39 @@ class UNet1DConditionModel(ParamTree):
             self._native.set_latency_mode(self._latency_mode)
 
     def set_gemm_mode(self, mode):
-        """"f32" (default): every conv / linear on the exact-fp32 MFMA.  "split_bf16": the same layers as fp32-equivalent split-bf16
-        GEMMs (three bf16 terms per operand, six products, fp32 accumulate; csrc/conv_bf3.hip) -- not part of the reference's API."""
-        if mode not in ("f32", "split_bf16", "split_f16"):
+        """"f32" (default): every conv / linear on the exact-fp32 MFMA.  "split_f16" (opt-in, experimental): the same layers with two fp16
+        terms per operand on the fp16 matrix pipe (22-bit operands, fp32 accumulate; csrc/conv_bf3.hip; precondition on the activations'
+        range: include/lds.h, check_split_f16_ranges) -- not part of the reference's API.  ("split_bf16" was removed in round 4.)"""
+        if mode == "split_bf16":
+            raise ValueError("the split_bf16 mode was removed (lossless, but no faster than exact fp32: DESIGN.md 10.1)")
+        if mode not in ("f32", "split_f16"):
             raise ValueError(mode)
         self._gemm_mode = mode
         if self._native is not None:
             self._native.set_gemm_mode(mode)
+
+    def check_split_f16_ranges(self, sample, timestep, lo=2.0 ** -3, hi=2.0 ** 15):
+        """Debug aid for the split_f16 mode's precondition (include/lds.h): one traced forward of these inputs (include/lds_test.h
+        lds_debug_trace: synchronises after every stage; not for the timed path), the abs-max of every tensor the mode stores as two fp16 planes.
+        Returns [(stage, absmax)]; raises ValueError naming the stages whose abs-max lies outside [lo, hi] -- above: fp16 overflow ahead; below:
+        the second fp16 term goes subnormal and the tensor keeps fewer than 22 bits.  Works in either GEMM mode (the ranges are the model's)."""
+        B = sample.shape[0]
+        native.debug_trace(True)
+        try:
+            self.forward(sample, timestep)
+        finally:
+            native.debug_trace(False)
+        ranges = []
+        for name, raw in native.debug_trace_records():
+            if name.count("|") != 3:
+                continue      # fp32 tensors of every mode: q / k / v, eps
+            nm, arr = native.debug_trace_decode(name, raw, B)
+            ranges.append((nm, float(abs(arr).max())))
+        bad = [(nm, m) for nm, m in ranges if not (lo <= m <= hi)]
+        if bad:
+            raise ValueError("split_f16 precondition: tensors with an abs-max outside [%g, %g]: %s" % (lo, hi, ", ".join("%s %.3g" % b for b in bad[:12])
+                                                                                                     + (" ... (%d in all)" % len(bad) if len(bad) > 12 else "")))
+        return ranges
 
     def forward(self, sample, timestep, **kwargs):
         """sample [B, M+H, T] (x stacked on cond, reference diffusion.py:105), timestep [B] or scalar."""

@@ -96,15 +96,16 @@ class Unit2Mel(nn.Module):
         return self._embed
 
     def forward(self, units, volume, spk_id=None, aug_shift=None, gt_spec=None, infer=True, infer_speedup=10, method="unipc",
-                use_tqdm=False):
-        return self._forward(units, volume, spk_id, aug_shift, gt_spec, infer, infer_speedup, method, None)
+                use_tqdm=False, *, x_T=None):
+        """reference unit2mel.py:73 plus the optional x_T of GaussianDiffusion.forward (the start noise, given instead of drawn)"""
+        return self._forward(units, volume, spk_id, aug_shift, gt_spec, infer, infer_speedup, method, None, x_T)
 
-    def forward_ragged(self, units, lengths, spk_id=None, infer_speedup=10, method="unipc"):
+    def forward_ragged(self, units, lengths, spk_id=None, infer_speedup=10, method="unipc", x_T=None):
         """Extension (not in the reference): units [B, T, C] padded to the longest utterance + the utterances' own frame counts -> mel
         [B, T, M] with zeros beyond each length; every utterance as if it ran alone (GaussianDiffusion.forward_ragged)."""
-        return self._forward(units, None, spk_id, None, None, True, infer_speedup, method, lengths)
+        return self._forward(units, None, spk_id, None, None, True, infer_speedup, method, lengths, x_T)
 
-    def _forward(self, units, volume, spk_id, aug_shift, gt_spec, infer, infer_speedup, method, lengths):
+    def _forward(self, units, volume, spk_id, aug_shift, gt_spec, infer, infer_speedup, method, lengths, x_T=None):
         # reference unit2mel.py:74-77: volume_embed is None, so a non-None volume cannot be embedded there either
         if volume is not None:
             raise NotImplementedError("volume_embed is None in the reference (unit2mel.py:55); pass volume=None")
@@ -126,5 +127,5 @@ class Unit2Mel(nn.Module):
         cond = self._native_embed().forward(units.contiguous().float(), spk_id)        # [B,H,T]
         x = native.transpose(cond)                                                     # [B,T,H] as the reference hands over
         if lengths is not None:
-            return self.decoder.forward_ragged(x, lengths, gt_spec=gt_spec, infer_speedup=infer_speedup, method=method)
-        return self.decoder(x, gt_spec=gt_spec, infer=infer, infer_speedup=infer_speedup, method=method, use_tqdm=False)
+            return self.decoder.forward_ragged(x, lengths, gt_spec=gt_spec, infer_speedup=infer_speedup, method=method, x_T=x_T)
+        return self.decoder(x, gt_spec=gt_spec, infer=infer, infer_speedup=infer_speedup, method=method, use_tqdm=False, x_T=x_T)

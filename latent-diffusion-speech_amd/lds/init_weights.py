@@ -47,7 +47,28 @@ def _fan_in(shape):
     return int(np.prod(shape[1:]))
 
 
+_DEFERRED = [False]
+
+
+class deferred:
+    """`with init_weights.deferred():` -- modules built inside get zero tensors instead of the seeded values: ranks >= 1 of a multi-GPU job
+    receive rank 0's weights by one broadcast (lds/shard.py broadcast_state) instead of generating them again."""
+
+    def __enter__(self):
+        self.prev = _DEFERRED[0]
+        _DEFERRED[0] = True
+
+    def __exit__(self, *a):
+        _DEFERRED[0] = self.prev
+
+
 def init_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
+    if _DEFERRED[0]:
+        return np.zeros(shape, dtype=np.float32)
+    return _init_tensor(name, shape, seed)
+
+
+def _init_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
     """Role-based scale: norm gains ~1, norm/linear biases small, matrices/conv kernels
     uniform(+-1/sqrt(fan_in)) (the familiar default scale), embeddings unit variance."""
     leaf = name.rsplit(".", 2)

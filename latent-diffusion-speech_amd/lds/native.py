@@ -162,8 +162,8 @@ class UNet:
             self.h = None
 
     def set_gemm_mode(self, mode):
-        """0 / "f32": exact-fp32 MFMA (default); 1 / "split_bf16": fp32-equivalent split-bf16 GEMMs (include/lds.h)"""
-        m = {"f32": 0, "split_bf16": 1, "split_f16": 2}.get(mode, mode)
+        """0 / "f32": exact-fp32 MFMA (default); 2 / "split_f16": two fp16 terms per operand (opt-in; include/lds.h)"""
+        m = {"f32": 0, "split_bf16": 1, "split_f16": 2}.get(mode, mode)      # (1 is refused by the library: removed mode)
         check(lib().lds_unet_set_gemm_mode(self.h, int(m)))
 
     def gemm_mode(self):
@@ -289,6 +289,30 @@ def debug_trace_records():
         check(lib().lds_debug_trace_get(i, name, C.c_size_t(len(name)), C.byref(ptr), C.byref(nb)))
         out.append((name.value.decode(), C.string_at(ptr, nb.value)))
     return out
+
+
+def debug_trace_decode(name, raw, B):
+    """one debug-trace record -> (stage name, plain [B, C, T] float32 array; a flat float32 array for records that are not activation tensors)"""
+    parts = name.split("|")
+    if len(parts) != 4:
+        return name, np.frombuffer(raw, dtype=np.float32).copy()
+    nm, Cc, T, mode = parts[0], int(parts[1]), int(parts[2]), int(parts[3])
+    if mode == 0:      # K4P: [B][C/8][2][T+2][4], channel 8q + 2j + h
+        a = np.frombuffer(raw, dtype=np.float32).reshape(B, Cc // 8, 2, T + 2, 4)
+        out = np.empty((B, Cc // 8, 8, T), dtype=np.float32)
+        for h in range(2):
+            for j in range(4):
+                out[:, :, 2 * j + h] = a[:, :, h, 1:T + 1, j]
+        return nm, out.reshape(B, Cc, T)
+    npl = 3 if mode == 1 else 2      # split planes [B][C/8][planes][T+2][8]: bf16 x 3 or fp16 x 2
+    if mode == 1:
+        a = (np.frombuffer(raw, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(B, Cc // 8, npl, T + 2, 8)
+    else:
+        a = np.frombuffer(raw, dtype=np.float16).astype(np.float32).reshape(B, Cc // 8, npl, T + 2, 8)
+    v = a[:, :, 0].copy()
+    for pl in range(1, npl):
+        v = v + a[:, :, pl]
+    return nm, np.ascontiguousarray(v[:, :, 1:T + 1].transpose(0, 1, 3, 2)).reshape(B, Cc, T)
 
 
 def prof_enable(level=1):

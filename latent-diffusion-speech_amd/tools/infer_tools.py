@@ -36,7 +36,7 @@ class DiffusionSVC:
         return torch.nn.functional.pad(out_wav, (start_frame * self.vocoder.vocoder_hop_size, 0))
 
     @torch.no_grad()
-    def __call__(self, units, f0=None, volume=None, spk_id=1, aug_shift=0, gt_spec=None, infer_speedup=10, method="unipc", use_tqdm=True):
+    def __call__(self, units, f0=None, volume=None, spk_id=1, aug_shift=0, gt_spec=None, infer_speedup=10, method="unipc", use_tqdm=True, x_T=None):
         """reference infer_tools.py:70-74: units [B,T,C] -> mel [B,T,M]; f0 is unused by the TTS model and must be None"""
         if f0 is not None:
             raise NotImplementedError("the TTS Unit2Mel has no f0 input (22_infer_tts.py passes f0=None)")
@@ -46,18 +46,18 @@ class DiffusionSVC:
         else:
             sid = torch.LongTensor(np.full((B, 1), int(spk_id))).to(self.device)
         return self.model(units.to(self.device), volume, spk_id=sid, aug_shift=None, gt_spec=gt_spec, infer=True,
-                          infer_speedup=infer_speedup, method=method, use_tqdm=use_tqdm)
+                          infer_speedup=infer_speedup, method=method, use_tqdm=use_tqdm, x_T=x_T)
 
     @torch.no_grad()
-    def call_ragged(self, units, lengths, spk_id=1, infer_speedup=10, method="unipc"):
+    def call_ragged(self, units, lengths, spk_id=1, infer_speedup=10, method="unipc", x_T=None):
         """Extension: a padded ragged batch of units [B,T,C] + per-utterance frame counts -> mel [B,T,M] (Unit2Mel.forward_ragged)"""
         B = units.shape[0]
         sid = spk_id.to(self.device).long().reshape(B, -1) if torch.is_tensor(spk_id) else torch.LongTensor(np.full((B, 1), int(spk_id))).to(self.device)
-        return self.model.forward_ragged(units.to(self.device), lengths, spk_id=sid, infer_speedup=infer_speedup, method=method)
+        return self.model.forward_ragged(units.to(self.device), lengths, spk_id=sid, infer_speedup=infer_speedup, method=method, x_T=x_T)
 
     @torch.no_grad()
-    def infer(self, units, f0=None, volume=None, gt_spec=None, spk_id=1, aug_shift=0, infer_speedup=10, method="unipc", use_tqdm=True):
+    def infer(self, units, f0=None, volume=None, gt_spec=None, spk_id=1, aug_shift=0, infer_speedup=10, method="unipc", use_tqdm=True, x_T=None):
         """reference infer_tools.py:77-81: units -> waveform [B,1,T*hop]"""
         out_mel = self.__call__(units, f0, volume, spk_id=spk_id, aug_shift=aug_shift, gt_spec=None, infer_speedup=infer_speedup,
-                                method=method, use_tqdm=use_tqdm)
+                                method=method, use_tqdm=use_tqdm, x_T=x_T)
         return self.mel2wav(out_mel, f0)

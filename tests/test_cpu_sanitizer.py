@@ -24,9 +24,14 @@ for (B, T) in ((16, 512), (1, 77), (3, 2050)):
     native.check(L.lds_unet_workspace_bytes(u.h, B, T, C.byref(nb))); a = nb.value
     native.check(L.lds_sampler_workspace_bytes(u.h, B, T, C.byref(nb))); assert nb.value > a > 0
 f32 = nb.value
-u.set_gemm_mode("split_bf16")                       # packs the three-plane twins of every weight set
-assert u.gemm_mode() == 1
-native.check(L.lds_sampler_workspace_bytes(u.h, 3, 2050, C.byref(nb))); assert nb.value > f32
+try:
+    u.set_gemm_mode("split_bf16")                  # the removed mode: refused
+    raise SystemExit("split_bf16 was accepted")
+except RuntimeError:
+    pass
+u.set_gemm_mode("split_f16")                       # packs the two-plane twins of every weight set
+assert u.gemm_mode() == 2
+native.check(L.lds_sampler_workspace_bytes(u.h, 3, 2050, C.byref(nb))); assert nb.value >= f32
 u.set_gemm_mode("f32")
 assert L.lds_unet_set_gemm_mode(u.h, 7) == -1 and L.lds_unet_workspace_bytes(u.h, 0, 5, C.byref(nb)) == -1
 # ragged batches: the per-utterance lengths are validated before anything is launched

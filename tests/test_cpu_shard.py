@@ -71,3 +71,44 @@ def test_scatter_gather_world2_gloo(n_items):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _bcast_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, PKG)
+    from lds import init_weights, shard
+    from lds.paramtree import ParamTree
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = {"a.weight": (5, 3), "a.bias": (5,), "b.c.weight": (2, 2, 4)}
+        import contextlib
+        with (init_weights.deferred() if rank else contextlib.nullcontext()):
+            m = ParamTree(shapes, seed=0)                        # rank 0: the seeded values; the others: zeros
+        m.register_buffer("steps", torch.tensor([3], dtype=torch.int64))      # non-float entries stay local
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        moved = shard.broadcast_state(m.state_dict(), rank, world)
+        want = {k: torch.from_numpy(init_weights.init_tensor(k, s, 0)) for k, s in shapes.items()}
+        ok = moved == 4 * (15 + 5 + 16)
+        ok = ok and all(torch.equal(m.state_dict()[k], want[k]) for k in shapes)
+        if rank:
+            ok = ok and all(float(before[k].abs().max()) == 0.0 for k in shapes)      # it really was built empty
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_state_world3_gloo():
+    """ranks >= 1 build their modules empty (init_weights.deferred) and receive rank 0's weights by one broadcast"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 77
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True), (2, True)]

@@ -125,7 +125,7 @@ def unet_any():
 
 @pytest.mark.parametrize("B,T", [(1, 2050), (2, 1000), (1, 77), (5, 512)])
 @pytest.mark.parametrize("latency", [False, True])
-@pytest.mark.parametrize("mode", ["f32", "split_bf16", "split_f16"])
+@pytest.mark.parametrize("mode", ["f32", "split_f16"])
 def test_unet_poisoned_workspace(unet_any, mode, latency, B, T):
     """the whole caller workspace filled with zeros / a NaN pattern (fp32, fp16 and bf16 alike) / finite patterns before the call: finite and
     bit-identical results -- a kernel that reads a slot no kernel of the call wrote, or whose result depends on timing, shows here"""

@@ -18,28 +18,8 @@ for p in (os.path.join(ROOT, "latent-diffusion-speech_amd"), ROOT):
 
 
 def decode(name, raw, B):
-    """record -> (stage name, plain [B, C, T] float32 array or a flat float32 array)"""
-    parts = name.split("|")
-    if len(parts) != 4:
-        return name, np.frombuffer(raw, dtype=np.float32).copy()
-    nm, C, T, mode = parts[0], int(parts[1]), int(parts[2]), int(parts[3])
-    if mode == 0:      # K4P: [B][C/8][2][T+2][4], channel 8q + 2j + h
-        a = np.frombuffer(raw, dtype=np.float32).reshape(B, C // 8, 2, T + 2, 4)
-        out = np.empty((B, C // 8, 8, T), dtype=np.float32)
-        for h in range(2):
-            for j in range(4):
-                out[:, :, 2 * j + h] = a[:, :, h, 1:T + 1, j]
-        return nm, out.reshape(B, C, T)
-    npl = 3 if mode == 1 else 2
-    if mode == 1:      # bf16 planes
-        u = np.frombuffer(raw, dtype=np.uint16).astype(np.uint32) << 16
-        a = u.view(np.float32).reshape(B, C // 8, npl, T + 2, 8)
-    else:
-        a = np.frombuffer(raw, dtype=np.float16).astype(np.float32).reshape(B, C // 8, npl, T + 2, 8)
-    v = a[:, :, 0].copy()
-    for pl in range(1, npl):
-        v = v + a[:, :, pl]
-    return nm, np.ascontiguousarray(v[:, :, 1:T + 1].transpose(0, 1, 3, 2)).reshape(B, C, T)
+    from lds import native
+    return native.debug_trace_decode(name, raw, B)
 
 
 def traced_forward(unet, x, t, B, fill=None):
