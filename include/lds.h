@@ -18,8 +18,10 @@
  *     never synchronise the device (host arrays they are handed -- the sampler's table -- are copied into
  *     the launches' kernel arguments during the call).  Exceptions, documented at the function:
  *     lds_lm_generate polls for EOS, *_create upload weights, lds_prof_summary reads events.
- *     Handles are immutable after create, so calls on different streams are safe as long as each
- *     has its own workspace.
+ *     Handles are immutable after create EXCEPT for the two mode switches of the denoiser (lds_unet_set_gemm_mode,
+ *     lds_unet_set_latency_mode): calls on different streams / threads are safe as long as each has its own
+ *     workspace and nobody switches a mode meanwhile -- a switch while another thread is inside a forward or
+ *     sampler call of the same handle is refused with LDS_EBUSY (the handle counts the calls in progress).
  *   - return value 0 = ok, negative LDS_E* on error; lds_last_error() gives the message
  *     (thread-local).  Nothing throws or aborts.
  */
@@ -38,6 +40,7 @@ extern "C" {
 #define LDS_ENOMEM (-2)    /* workspace too small or device allocation failed */
 #define LDS_EHIP (-3)      /* a HIP runtime call failed */
 #define LDS_EMISSING (-4)  /* a required weight tensor was not supplied */
+#define LDS_EBUSY (-5)     /* a mode switch while another thread is inside a forward / sampler call of the same handle */
 
 typedef struct lds_unet lds_unet;
 typedef struct lds_embed lds_embed;

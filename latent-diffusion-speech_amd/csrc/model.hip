@@ -773,6 +773,12 @@ struct lds_unet {
     int gemm_mode = LDS_GEMM_F32;      // LDS_GEMM_SPLIT_BF16 / LDS_GEMM_SPLIT_F16: every conv / linear through conv_bf3 (lds_unet_set_gemm_mode)
     bool split_packed[2] = {false, false};
     int latency_mode = 0;              // 1: tile / split choices from the actual batch (lds_unet_set_latency_mode)
+    std::atomic<int> in_calls{0};      // forward / sampler calls of any thread currently enqueueing on this handle (the mode switches refuse meanwhile)
+};
+struct UnetCallScope {      // RAII: one call in progress
+    lds_unet* u;
+    explicit UnetCallScope(lds_unet* u_) : u(u_) { u->in_calls.fetch_add(1, std::memory_order_acq_rel); }
+    ~UnetCallScope() { u->in_calls.fetch_sub(1, std::memory_order_acq_rel); }
 };
 
 static float* up_vec(Owner& o, const float* p, int64_t n) {
@@ -1062,6 +1068,7 @@ extern "C" int lds_unet_set_gemm_mode(lds_unet* u, int mode) {
     if (u && mode == LDS_GEMM_SPLIT_BF16)
         return fail(LDS_EINVAL, "the split-bf16 UNet mode was removed in round 4: lossless but no faster than exact fp32 (DESIGN 10.1); the kernel format remains (lds_test_dconv_split)");
     if (!u || (mode != LDS_GEMM_F32 && mode != LDS_GEMM_SPLIT_F16)) return fail(LDS_EINVAL, "bad argument");
+    if (u->in_calls.load(std::memory_order_acquire) > 0) return fail(LDS_EBUSY, "a forward / sampler call of this handle is in progress on another thread");
     if (mode != LDS_GEMM_F32 && !u->split_packed[mode - 1]) {
         if (u->M % 16 || u->H % 16) return fail(LDS_EINVAL, "split GEMM modes need out_dims and n_hidden to be multiples of 16");
         if (!unet_pack_split(u, mode - 1)) return fail(LDS_ENOMEM, "packing the split weights failed");
@@ -1073,6 +1080,7 @@ extern "C" int lds_unet_set_gemm_mode(lds_unet* u, int mode) {
 extern "C" int lds_unet_get_gemm_mode(const lds_unet* u) { return u ? u->gemm_mode : LDS_EINVAL; }
 extern "C" int lds_unet_set_latency_mode(lds_unet* u, int on) {
     if (!u || (on != 0 && on != 1)) return fail(LDS_EINVAL, "bad argument");
+    if (u->in_calls.load(std::memory_order_acquire) > 0) return fail(LDS_EBUSY, "a forward / sampler call of this handle is in progress on another thread");
     u->latency_mode = on;
     return LDS_OK;
 }
@@ -1345,6 +1353,7 @@ static int unet_stage_cond(lds_unet* u, const float* cond, void* ws, size_t ws_b
 static int unet_forward_impl(lds_unet* u, const float* x, const float* cond, const float* t, float* eps, void* ws, size_t ws_bytes,
                              int B, int T, hipStream_t st, bool uniform_t = false, const float* tproj_pre = nullptr,
                              bool cond_staged = false, const int* lens_host = nullptr) {
+    UnetCallScope in_call(u);
     Arena A(ws, ws_bytes);
     UnetWs w;
     plan_ws(u, A, B, T, w);
@@ -1529,6 +1538,7 @@ extern "C" int lds_sampler_run_ragged(lds_unet* u, int method, int n_rows, const
 static int sampler_run_impl(lds_unet* u, int method, int n_rows, const float* table, const float* cond, float* x, const float* noise, void* ws, size_t ws_bytes,
                             int B, int T, void* stream, const int* lens) {
     if (!u || !table || !cond || !x || !ws || n_rows <= 0 || B <= 0 || T <= 0) return fail(LDS_EINVAL, "bad argument");
+    UnetCallScope in_call(u);
     hipStream_t st = (hipStream_t)stream;
     ProfChain chain;
     Arena A(ws, ws_bytes);

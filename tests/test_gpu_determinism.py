@@ -187,3 +187,38 @@ def test_sampler_poisoned_workspace(method, speedup):
                 torch.randn = real
         assert all(torch.isfinite(o).all() for o in outs)
         assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+
+
+def test_mode_switch_refused_while_a_call_is_in_progress():
+    """include/lds.h: the two mode switches are the only mutable state of a denoiser handle; while another thread is inside a sampler call of the
+    handle they return LDS_EBUSY instead of changing the plan under it (and work again afterwards)"""
+    import threading
+    from diffusion.unit2mel import Unit2Mel
+    from lds import init_weights
+    m = Unit2Mel(1280, 323, 80).to("cuda").eval()
+    gd = m.decoder
+    cond = torch.from_numpy(init_weights.uniform("busy.cond", (1, 256, 256), 5, -1, 1)).cuda()
+    gd(cond, infer=True, infer_speedup=500, method="dpm-solver")      # creates and packs the native handle
+    torch.cuda.synchronize()
+    nat = gd.denoise_fn.native()
+    refused, done = [], threading.Event()
+
+    def run():
+        try:
+            for _ in range(3):
+                gd(cond, infer=True, infer_speedup=10, method="dpm-solver")      # 100 evaluations: ~25 k launches enqueued per call
+        finally:
+            done.set()
+
+    th = threading.Thread(target=run)
+    th.start()
+    while not done.is_set():
+        try:
+            nat.set_latency_mode(False)      # (the value it already has: a refused or an accepted call changes nothing)
+        except RuntimeError as e:
+            refused.append(str(e))
+    th.join()
+    torch.cuda.synchronize()
+    assert refused and "in progress" in refused[0], "no switch was refused while the sampler call was enqueueing"
+    nat.set_latency_mode(True)
+    nat.set_latency_mode(False)
