@@ -186,8 +186,9 @@ int lds_lm_workspace_bytes(const lds_lm* lm, int B, int L, int max_length, size_
 int lds_lm_encode(lds_lm* lm, const int64_t* phone, const int64_t* tone, const int64_t* spk_id, const int32_t* enc_len, float* enc, void* ws,
                   size_t ws_bytes, int B, int L, void* stream);
 /* Roformer.generate (roformer.py:179-240): greedy (do_sample 0) or RepetitionPenalty -> Temperature -> TopK -> TopP -> one draw per
- * step.  enc_len as above (roformer.py:229-236: encoder_attention_mask on the decoder's cross-attention) or NULL.  top_k: 1 .. 64, exactly
- * k candidates survive (ties towards the lower id; HF also keeps logits tied with the k-th and accepts 0 / None = no filter -- not built).
+ * step.  enc_len as above (roformer.py:229-236: encoder_attention_mask on the decoder's cross-attention) or NULL.  top_k as HF's
+ * TopKLogitsWarper: 1 .. 64 keeps the k largest scores AND every score tied with the k-th (up to 64 survivors in all); 0 (HF: None / 0) applies
+ * no top-k filter -- softmax, the nucleus cut and the draw then run over the whole vocabulary (a slower, optional path).
  * uniforms dev [max_length-1][B]: the draw is the inverse-CDF rule over the vocabulary order with these numbers (torch's own
  * multinomial stream cannot be reproduced outside torch).  tokens dev int64 [B][max_length] (BOS first; finished sequences padded);
  * logits_out optional dev [max_length-1][B][sem_vocab]; *n_tokens_host = length of the returned sequences incl. BOS.  The call

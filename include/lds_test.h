@@ -107,6 +107,11 @@ int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, voi
 int lds_test_gn_apply_bf3(const float* x1, const float* x2, int C1, int C2, int T, int groups, float eps, const float* gamma,
                           const float* beta, const float* scale_shift, int silu, float* out, int B, void* stream);
 
+/* ONE token choice per row of logits [B][V] (dev) with the kernels of lds_lm_generate, after a history hist [B][n_hist] int64 (dev; what the repetition
+ * penalty looks at); uniforms [B] (dev); out [B] int64 (dev).  top_k 0 = no top-k filter (HF: None / 0), else 1 .. 64 with ties of the k-th kept. */
+int lds_test_lm_sample(const float* logits, int B, int V, int do_sample, int top_k, float top_p, float temperature, float repetition_penalty,
+                       const float* uniforms, const int64_t* hist, int n_hist, int64_t* out, void* stream);
+
 /* ---- debugging aids (tests/test_gpu_poison.py, tools/diag_trace.py) ----------------------------------------------------------
  * lds_debug_fill_u32: every 32-bit word of a device buffer = pattern.  Tests fill a caller workspace with NaN patterns (0x7fc07fc0 is a NaN
  * as fp32 and as two fp16 / bf16 halves) before a call: a kernel that reads a slot no kernel of THAT call wrote turns it into a NaN (or, behind

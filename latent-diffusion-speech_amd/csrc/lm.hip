@@ -418,8 +418,11 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < NI; ++i) v[i] *= inv_temp;
     }
+    // TopKLogitsWarper removes the scores BELOW the k-th largest (modeling: `scores < topk(scores, k)[..., -1]`), so every score tied with the
+    // k-th one survives too: the selection runs on past k rounds while the next maximum still equals the k-th value (up to kMaxTopK survivors).
     const int rounds = do_sample ? top_k : 1;
-    for (int r = 0; r < rounds; ++r) {      // r-th largest remaining value, ties to the lowest index
+    int n_sel = rounds;
+    for (int r = 0; r < (do_sample ? kMaxTopK : 1); ++r) {      // r-th largest remaining value, ties to the lowest index
         float bv = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
@@ -439,6 +442,11 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+        if (r >= rounds) {      // (bv, topv are the same in every thread: the loop's exit is uniform)
+            __syncthreads();
+            if (!(bv == topv[rounds - 1]) || !(bv > -INFINITY)) { n_sel = r; break; }
+            n_sel = r + 1;
+        }
         if (tid == 0) { topv[r] = bv; topi[r] = bi; }
         if ((bi & 255) == tid) {
 #pragma unroll
@@ -453,7 +461,7 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
             next = topi[0];
         } else {
             // softmax over the survivors (descending order in topv), optional nucleus cut, renormalise, draw in vocabulary order
-            int kept = top_k;
+            int kept = n_sel;
             float sum = 0.f;
             for (int j = 0; j < kept; ++j) { pr[j] = expf(topv[j] - topv[0]); sum += pr[j]; }
             if (top_p < 1.0f) {      // TopPLogitsWarper: drop the tail whose ascending cumulative probability stays <= 1 - top_p
@@ -493,6 +501,114 @@ __global__ void __launch_bounds__(256) lm_sample_kernel(const float* __restrict_
     }
     // the next decode step's input row, LayerNorm(word[next] + type[0]) (what lm_embed_kernel computes), without a launch of its own
     if (xnext) {
+        __syncthreads();
+        long long t = chosen;
+        t = (t < 0) ? 0 : (t >= V ? V - 1 : t);
+        float ev[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            ev[i] = (c < H) ? word[t * H + c] + type[c] : 0.f;
+            s += ev[i];
+        }
+        const float mean = block_sum256(s, rv) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dd = (tid + 256 * i < H) ? ev[i] - mean : 0.f; q += dd * dd; }
+        const float rstd = 1.0f / sqrtf(block_sum256(q, rv) / (float)H + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if (c < H) xnext[(long long)b * H + c] = (ev[i] - mean) * rstd * eg[c] + eb[c];
+        }
+    }
+}
+
+// ---- the same choice with NO top-k filter (HF: top_k = None / 0): RepetitionPenalty -> Temperature -> [TopP] -> softmax -> one draw over the whole
+//      vocabulary.  An optional path (the reference's caller passes top_k = 5): the softmax normalisation and the inverse-CDF walk are serial loops of
+//      one thread over an LDS copy of the row (~4 k adds each: tens of microseconds), in vocabulary order -- exactly what a sequential float32
+//      cumsum computes, so the oracle restates it to the bit.  TopP (modeling: sort ascending, drop while the cumulative probability stays
+//      <= 1 - top_p, always keep the largest): the cut is found as the largest probability value t with sum{p_j <= t} <= 1 - top_p by bisection
+//      over the ordered bit patterns of the probabilities (31 block reductions); probabilities tied with the cut are dropped together. ----
+__global__ void __launch_bounds__(256) lm_sample_full_kernel(const float* __restrict__ logits, int V, float top_p, float inv_temp, float rep_pen,
+                                                             const float* __restrict__ uniforms, int64_t* __restrict__ tokens, int cap_tokens, int step,
+                                                             int* __restrict__ unfinished, int eos, int pad, int* __restrict__ any_unfinished,
+                                                             const float* __restrict__ word, const float* __restrict__ type, const float* __restrict__ eg,
+                                                             const float* __restrict__ eb, float eps, int H, float* __restrict__ xnext) {
+    extern __shared__ float prob[];      // [V]
+    __shared__ float rv[4];
+    __shared__ int chosen;
+    __shared__ float sh_max, sh_z;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* lg = logits + (long long)b * V;
+    int64_t* seq = tokens + (long long)b * cap_tokens;
+    for (int c = tid; c < V; c += 256) prob[c] = lg[c];
+    __syncthreads();
+    if (rep_pen != 1.0f && tid == 0) {      // every distinct token of the sequence so far, once (a token met again finds its score already changed: marked by a NaN-free sentinel list)
+        for (int j = 0; j <= step; ++j) {
+            const int t = (int)seq[j];
+            bool seen = false;
+            for (int q = 0; q < j; ++q) seen = seen || ((int)seq[q] == t);
+            if (!seen && t >= 0 && t < V) prob[t] = (prob[t] < 0.f) ? prob[t] * rep_pen : prob[t] / rep_pen;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int c = tid; c < V; c += 256) {
+        if (inv_temp != 1.0f) prob[c] *= inv_temp;
+        m = fmaxf(m, prob[c]);
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 63) rv[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) sh_max = fmaxf(fmaxf(rv[0], rv[1]), fmaxf(rv[2], rv[3]));
+    __syncthreads();
+    for (int c = tid; c < V; c += 256) prob[c] = expf(prob[c] - sh_max);
+    __syncthreads();
+    if (tid == 0) {
+        float z = 0.f;
+        for (int c = 0; c < V; ++c) z += prob[c];
+        sh_z = z;
+    }
+    __syncthreads();
+    for (int c = tid; c < V; c += 256) prob[c] = prob[c] / sh_z;
+    __syncthreads();
+    if (top_p < 1.0f) {
+        unsigned lo = 0u, hi = __float_as_uint(1.0f / sh_z);      // bit patterns of non-negative floats are ordered like the values; the largest p = 1 / z
+        // largest t in [lo, hi) with f(t) = sum{p_j : bits(p_j) <= t} <= 1 - top_p; f(0) = 0 always qualifies (p = +0 entries)
+        while (lo + 1 < hi) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            float s = 0.f;
+            for (int c = tid; c < V; c += 256) s += (__float_as_uint(prob[c]) <= mid) ? prob[c] : 0.f;
+            s = block_sum256(s, rv);
+            if (s <= 1.0f - top_p) lo = mid; else hi = mid;
+            __syncthreads();
+        }
+        for (int c = tid; c < V; c += 256)
+            if (__float_as_uint(prob[c]) <= lo) prob[c] = 0.f;      // (the largest probability has the pattern hi's upper end: never dropped)
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int alive = unfinished[b];
+        float z = 0.f;
+        for (int c = 0; c < V; ++c) z += prob[c];
+        const float u = uniforms[b];
+        float cs = 0.f;
+        int next = -1, last = pad;
+        for (int c = 0; c < V; ++c) {
+            if (prob[c] > 0.f) last = c;
+            cs += prob[c] / z;
+            if (cs > u) { next = c; break; }
+        }
+        if (next < 0) next = last;      // (rounding left the running sum at or below u: the last candidate)
+        if (!alive) next = pad;
+        seq[step + 1] = next;
+        chosen = next;
+        if (alive && next == eos) unfinished[b] = 0;
+        if (alive && next != eos) atomicOr(any_unfinished + step, 1);
+    }
+    if (xnext) {      // the next decode step's input row, as lm_sample_kernel writes it
         __syncthreads();
         long long t = chosen;
         t = (t < 0) ? 0 : (t >= V ? V - 1 : t);
@@ -773,8 +889,9 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, const int32_t* enc_
                                void* ws, size_t ws_bytes, void* stream) {
     if (!lm || !enc || !tokens || !n_tokens_host || !ws || B <= 0 || L <= 0 || max_length < 2) return lm_fail(LDS_EINVAL, "bad argument");
     const lds_lm_cfg& c = lm->cfg;
-    if (do_sample && (!uniforms || top_k < 1 || top_k > kMaxTopK || top_k > c.sem_vocab || !(top_p > 0.f) || !(temperature > 0.f)))
-        return lm_fail(LDS_EINVAL, "sampling needs uniforms, 1 <= top_k <= %d, top_p > 0, temperature > 0", kMaxTopK);
+    if (do_sample && (!uniforms || top_k < 0 || top_k > kMaxTopK || top_k > c.sem_vocab || !(top_p > 0.f) || !(temperature > 0.f)))
+        return lm_fail(LDS_EINVAL, "sampling needs uniforms, 0 <= top_k <= %d (0 = no top-k filter), top_p > 0, temperature > 0", kMaxTopK);
+    if (do_sample && top_k == 0 && (size_t)c.sem_vocab * sizeof(float) > 60 * 1024) return lm_fail(LDS_EINVAL, "top_k = 0 needs the vocabulary row in LDS (<= 15360 entries)");
     if (max_length > c.max_pos) return lm_fail(LDS_EINVAL, "max_length exceeds max_position_embeddings");
     // the encoder states come from lds_lm_encode (L <= max_pos); the cross-attention stages one score per encoder position in LDS
     if (L < 1 || L > c.max_pos || (size_t)(((L + 63) & ~63) + 4 * 34) * sizeof(float) > 64 * 1024)
@@ -826,7 +943,11 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, const int32_t* enc_
         const LmRows hrows{w.ctx, &lm->head_ln};
         float* lg = logits_out ? logits_out + (size_t)step * B * V : w.logits;
         LM_HIP(lm_dln<0>(lm->head_d, hrows, H, nullptr, c.eps, lg, V, B, st));
-        if (V <= 256 * 9)
+        if (do_sample && top_k == 0)
+            hipLaunchKernelGGL(lm_sample_full_kernel, dim3(B), dim3(256), sizeof(float) * V, st, lg, V, top_p, inv_temp, repetition_penalty, uniforms + (size_t)step * B,
+                               tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf, lm->dec.word, lm->dec.type, lm->dec.ln_emb.g, lm->dec.ln_emb.b,
+                               c.eps, H, w.x);
+        else if (V <= 256 * 9)
             hipLaunchKernelGGL(lm_sample_kernel<9>, dim3(B), dim3(256), 0, st, lg, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty,
                                do_sample ? uniforms + (size_t)step * B : nullptr, tokens, max_length, step, unfinished, c.sem_eos, c.sem_pad, any_unf,
                                lm->dec.word, lm->dec.type, lm->dec.ln_emb.g, lm->dec.ln_emb.b, c.eps, H, w.x);
@@ -852,4 +973,48 @@ extern "C" int lds_lm_generate(lds_lm* lm, const float* enc, const int32_t* enc_
     }
     *n_tokens_host = n_tokens;
     return LDS_OK;
+}
+
+// Test entry (include/lds_test.h): ONE token choice per row of `logits` [B][V] with the generate loop's own kernels, after a history of n_hist tokens
+// per row (hist [B][n_hist] int64, dev; what the repetition penalty looks at).  out [B] int64 (dev).  top_k 0 = no top-k filter.
+extern "C" int lds_test_lm_sample(const float* logits, int B, int V, int do_sample, int top_k, float top_p, float temperature, float repetition_penalty,
+                                  const float* uniforms, const int64_t* hist, int n_hist, int64_t* out, void* stream) {
+    if (!logits || !out || B <= 0 || V <= 0 || V > 256 * 32 || n_hist < 1 || !hist || (do_sample && !uniforms) || top_k < 0 || top_k > kMaxTopK) return lm_fail(LDS_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int cap = n_hist + 1;
+    int64_t* seq = nullptr;
+    int* flags = nullptr;
+    if (hipMalloc(&seq, sizeof(int64_t) * B * cap) != hipSuccess || hipMalloc(&flags, sizeof(int) * (B + cap)) != hipSuccess) return lm_fail(LDS_ENOMEM, "alloc");
+    std::vector<int> init(B + cap, 0);
+    for (int b = 0; b < B; ++b) init[b] = 1;
+    int rc = LDS_OK;
+    do {
+        if (hipMemcpy(flags, init.data(), sizeof(int) * (B + cap), hipMemcpyHostToDevice) != hipSuccess) { rc = lm_fail(LDS_EHIP, "copy"); break; }
+        if (hipMemcpy2DAsync(seq, sizeof(int64_t) * cap, hist, sizeof(int64_t) * n_hist, sizeof(int64_t) * n_hist, B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            rc = lm_fail(LDS_EHIP, "copy"); break;
+        }
+        const float inv_temp = do_sample ? 1.0f / temperature : 1.0f;
+        const int step = n_hist - 1;
+        const float* nf = nullptr;
+        if (do_sample && top_k == 0)
+            hipLaunchKernelGGL(lm_sample_full_kernel, dim3(B), dim3(256), sizeof(float) * V, st, logits, V, top_p, inv_temp, repetition_penalty, uniforms, seq, cap, step,
+                               flags, -1, -1, flags + B, nf, nf, nf, nf, 0.f, 0, (float*)nullptr);
+        else if (V <= 256 * 9)
+            hipLaunchKernelGGL(lm_sample_kernel<9>, dim3(B), dim3(256), 0, st, logits, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty, uniforms, seq, cap,
+                               step, flags, -1, -1, flags + B, nf, nf, nf, nf, 0.f, 0, (float*)nullptr);
+        else if (V <= 256 * 17)
+            hipLaunchKernelGGL(lm_sample_kernel<17>, dim3(B), dim3(256), 0, st, logits, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty, uniforms, seq, cap,
+                               step, flags, -1, -1, flags + B, nf, nf, nf, nf, 0.f, 0, (float*)nullptr);
+        else
+            hipLaunchKernelGGL(lm_sample_kernel<32>, dim3(B), dim3(256), 0, st, logits, V, do_sample, do_sample ? top_k : 1, top_p, inv_temp, repetition_penalty, uniforms, seq, cap,
+                               step, flags, -1, -1, flags + B, nf, nf, nf, nf, 0.f, 0, (float*)nullptr);
+        if (hipGetLastError() != hipSuccess) { rc = lm_fail(LDS_EHIP, "launch"); break; }
+        if (hipMemcpy2DAsync(out, sizeof(int64_t), seq + n_hist, sizeof(int64_t) * cap, sizeof(int64_t), B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            rc = lm_fail(LDS_EHIP, "copy"); break;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = lm_fail(LDS_EHIP, "sync");
+    } while (0);
+    (void)hipFree(seq);
+    (void)hipFree(flags);
+    return rc;
 }

@@ -125,10 +125,11 @@ class Roformer(ParamTree):
                  return_logits=False, **kwargs):
         if num_beams != 1 or no_repeat_ngram_size != 0 or end_gate_threshold is not None:
             raise NotImplementedError("beam search, n-gram blocking and the end gate are not built (22_infer_tts.py uses none of them)")
-        # top_k: 1 .. 64 when sampling (HF's TopKLogitsWarper also accepts None / 0 = no filter and keeps every logit tied with the k-th
-        # one; here exactly k candidates survive, ties broken towards the lower token id -- 22_infer_tts.py:83-98 passes top_k = 5)
-        if do_sample and not (top_k is not None and 1 <= int(top_k) <= 64):
-            raise NotImplementedError("sampling is built for 1 <= top_k <= 64")
+        # top_k as HF's TopKLogitsWarper: None / 0 = no filter (the draw runs over the whole vocabulary), k keeps the k largest scores and every
+        # score tied with the k-th (22_infer_tts.py:83-98 passes top_k = 5); more than 64 survivors are not built
+        top_k = 0 if top_k is None else int(top_k)
+        if do_sample and not (0 <= top_k <= 64):
+            raise NotImplementedError("sampling is built for top_k = None / 0 (no filter) or 1 <= top_k <= 64")
         enc_len = self._mask_to_lengths(attention_mask)      # reference roformer.py:209-236: the encoder's mask and the cross-attention's
         if not phone.is_cuda:
             raise RuntimeError("Roformer.generate needs tensors on a HIP device (no CPU fallback)")

@@ -140,6 +140,64 @@ def pick_token(logits, do_sample, top_k, u):
     return int(min(np.searchsorted(c, f32(u), side="right"), len(c) - 1))
 
 
+def pick_token_hf(logits, history, top_k, top_p, temperature, repetition_penalty, u):
+    """One draw the way HF's GenerationMixin._sample forms it (transformers logits_process.py): RepetitionPenaltyLogitsProcessor over the distinct
+    tokens of `history` -> TemperatureLogitsWarper -> TopKLogitsWarper (top_k None / 0: no filter; else scores BELOW the k-th largest are removed, so
+    ties of the k-th survive) -> TopPLogitsWarper (ascending order, drop while the cumulative probability stays <= 1 - top_p, keep the largest) ->
+    softmax -> inverse-CDF draw in vocabulary order with the uniform u (float32 sequential sums, like the kernels)."""
+    s = np.asarray(logits, dtype=f32).copy()
+    if repetition_penalty != 1.0:
+        for t in sorted(set(int(t) for t in history)):
+            s[t] = s[t] * f32(repetition_penalty) if s[t] < 0 else s[t] / f32(repetition_penalty)
+    if temperature != 1.0:
+        s = (s * f32(1.0 / temperature)).astype(f32)
+    if top_k:
+        # the survivors in descending order of score (equal scores: lower id first -- HF's own order among exactly equal scores is whatever
+        # torch.sort returns), softmax over them, the nucleus cut from the tail, the draw in vocabulary order
+        kth = np.sort(s)[-int(top_k)]
+        ids = np.nonzero(~(s < kth))[0]
+        ids = ids[np.lexsort((ids, -s[ids]))]
+        p = np.exp(s[ids] - s[ids][0]).astype(f32)
+        tot = f32(0)
+        for v in p:
+            tot = f32(tot + v)
+        kept = len(ids)
+        if top_p < 1.0:
+            tail, cut = f32(0), kept
+            for q in range(kept - 1, 0, -1):
+                tail = f32(tail + f32(p[q] / tot))
+                if tail <= f32(1.0) - f32(top_p):
+                    cut = q
+                else:
+                    break
+            kept = cut
+            tot = f32(0)
+            for v in p[:kept]:
+                tot = f32(tot + v)
+        ids, p = ids[:kept], (p[:kept] / tot).astype(f32)
+        o = np.argsort(ids)
+        c = np.cumsum(p[o], dtype=f32)
+        return int(ids[o][min(int(np.searchsorted(c, f32(u), side="right")), kept - 1)])
+    # no top-k filter: the whole vocabulary; the nucleus cut by VALUE (probabilities equal to the last dropped one go with it)
+    p = np.exp(s - s.max()).astype(f32)
+    p = (p / np.cumsum(p, dtype=f32)[-1]).astype(f32)
+    if top_p < 1.0:
+        order = np.argsort(p, kind="stable")                      # ascending
+        cum = np.cumsum(p[order].astype(np.float64))
+        drop = cum <= 1.0 - top_p
+        drop[-1] = False
+        if drop.any():
+            cutv = p[order][drop].max()
+            if cutv < p.max():
+                p = np.where(p <= cutv, f32(0), p)
+    z = np.cumsum(p, dtype=f32)[-1]
+    c = np.cumsum((p / z).astype(f32), dtype=f32)
+    k = int(np.searchsorted(c, f32(u), side="right"))
+    if k >= len(c):
+        k = int(np.nonzero(p > 0)[0][-1])
+    return k
+
+
 def generate(w, cfg, enc, max_length, do_sample=False, top_k=5, uniforms=None, enc_len=None):
     """GenerationMixin greedy / sampling loop as Roformer.generate drives it (roformer.py:179-240): starts from BOS, stops when every
     sequence has produced EOS or at max_length, finished sequences are padded.  Returns (tokens [B, n], logits [n-1, B, vocab])."""

@@ -364,3 +364,30 @@ def test_full_tts_path_phones_to_wav(tmp_path):
     np.save(tmp_path / "phones.npy", ph)
     wav = infer_tts.main(["--synthetic", "--phones", str(tmp_path / "phones.npy"), "--max_length", "17", "-s", "250", "-o", str(tmp_path / "o.npy")])
     assert wav.shape == (16 * 512,) and np.isfinite(wav).all()      # 17 - BOS tokens (random weights never emit EOS)
+
+
+@pytest.mark.parametrize("top_k,top_p,temp,pen", [(5, 1.0, 1.0, 1.0), (5, 0.8, 1.0, 1.2), (0, 1.0, 1.0, 1.0), (0, 0.8, 1.3, 1.2), (0, 0.5, 0.7, 1.0), (3, 1.0, 1.0, 1.0)])
+def test_token_choice_hf_semantics(top_k, top_p, temp, pen):
+    """the token choice of lds_lm_generate against HF's logits processors restated in numpy (oracle.roformer.pick_token_hf): top_k = 0 (HF: None / 0)
+    applies no top-k filter -- the nucleus cut and the draw run over the whole 4099-entry vocabulary --, and scores tied with the k-th largest
+    survive the top-k filter (rows 2 and 3 below carry such ties; reference roformer.py:216-227 forwards whatever the caller passes)"""
+    import ctypes as ct
+    from lds import native
+    from oracle import roformer as R
+    rng = np.random.default_rng(17)
+    B, V, NH = 6, 4099, 5
+    lg = (rng.standard_normal((B, V)) * 2.5).astype(np.float32)
+    lg[2, [7, 900, 4000]] = lg[2].max() + 1.0                    # three-way tie at the top: top_k = 3 keeps exactly them, top_k = 5 two more
+    k5 = np.sort(lg[3])[-5]
+    lg[3, [11, 12, 13]] = k5                                      # ties WITH the 5th largest: HF keeps all of them
+    hist = rng.integers(0, V, size=(B, NH)).astype(np.int64)
+    hist[1, 1] = hist[1, 3]                                       # a token met twice is penalised once
+    for draw in range(4):
+        u = rng.random(B).astype(np.float32)
+        out = torch.empty(B, dtype=torch.int64, device="cuda")
+        dl, du, dh = dev(lg), dev(u), torch.from_numpy(hist).cuda()
+        native.check(native.lib().lds_test_lm_sample(ct.c_void_p(dl.data_ptr()), B, V, 1, top_k, ct.c_float(top_p), ct.c_float(temp), ct.c_float(pen),
+                                                     ct.c_void_p(du.data_ptr()), ct.c_void_p(dh.data_ptr()), NH, ct.c_void_p(out.data_ptr()),
+                                                     ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        want = [R.pick_token_hf(lg[b], hist[b], top_k, top_p, temp, pen, u[b]) for b in range(B)]
+        assert out.cpu().tolist() == want, (draw, out.cpu().tolist(), want)
