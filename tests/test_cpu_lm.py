@@ -48,7 +48,7 @@ def test_roformer_loud_failures(lm):
     with pytest.raises(NotImplementedError, match="right-padded"):      # only ones-then-zeros masks are built
         lm.generate(ph, ph, attention_mask=torch.tensor([[1, 0, 1, 1]]))
     with pytest.raises(NotImplementedError, match="top_k"):
-        lm.generate(ph, ph, top_k=0)
+        lm.generate(ph, ph, top_k=65)      # (None / 0 = no filter and 1 .. 64 are built)
     assert lm._mask_to_lengths(torch.tensor([[1, 1, 1, 0], [1, 1, 1, 1]])).tolist() == [3, 4]
     with pytest.raises(NotImplementedError):
         lm(ph, ph, ph)
