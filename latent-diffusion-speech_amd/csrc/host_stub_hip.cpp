@@ -29,6 +29,10 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;
 }
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s_, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < height; ++r) memcpy((char*)d + r * dpitch, (const char*)s_ + r * spitch, width);
+    return hipSuccess;
+}
 hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t) {
     for (size_t i = 0; i < count; ++i) memcpy((char*)d + 4 * i, &v, 4);
     return hipSuccess;
