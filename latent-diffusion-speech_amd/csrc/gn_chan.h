@@ -34,28 +34,31 @@ static __device__ __forceinline__ void chan_step(float& n, float& mean, float& m
 // between the request and the use: gn_part_load = this lane's partial of round p0 (an empty one beyond the group's last),
 // gn_group_finish = the combination (further rounds are loaded there; P <= 64 partials -- every level of the UNet -- need none).
 struct GnPart { float n, mean, m2; };
-// Tv: valid frames of this batch element (ragged batches; = T otherwise): blocks beyond it are empty partials whatever the buffer holds
+// Tv: valid frames of this batch element (ragged batches; = T otherwise): blocks beyond it are empty partials whatever the buffer holds.
+// The load itself is UNCONDITIONAL (an out-of-range lane reads the group's first partial, a valid address) and only the count carries the mask:
+// a load inside a divergent branch is waited for at the end of that branch, and the fold's kernels want these requests in flight across the
+// issue of their first operand tiles (round 4: the ISA of the folded proj_in showed `s_waitcnt vmcnt(0)` right behind each request).  An
+// empty partial is n = 0 with a finite (mean, M2) that every consumer multiplies by its count or masks by it.
 static __device__ __forceinline__ GnPart gn_part_load(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, int p0, int Tv) {
     const int nT = (T + 31) >> 5, P = cg16 * nT;
     const int pi = p0 + lane;
-    GnPart r{0.f, 0.f, 0.f};
-    if (pi < P) {
-        const int kk = (int)(((float)pi + 0.5f) * (1.0f / (float)nT)), tb = pi - kk * nT, kb = g * cg16 + kk;      // pi / nT without the integer-division sequence
-        const int nv = (Tv - tb * 32 < 32) ? Tv - tb * 32 : 32;
-        if (nv > 0) {
-            const float2 pr = gp[((long long)b * (C >> 4) + kb) * nT + tb];
-            r.n = 16.0f * (float)nv; r.mean = pr.x; r.m2 = pr.y;
-        }
-    }
+    const bool in = pi < P;
+    const int pc = in ? pi : 0;
+    const int kk = (int)(((float)pc + 0.5f) * (1.0f / (float)nT)), tb = pc - kk * nT, kb = g * cg16 + kk;      // pc / nT without the integer-division sequence
+    const int nv = (Tv - tb * 32 < 32) ? Tv - tb * 32 : 32;
+    const float2 pr = gp[((long long)b * (C >> 4) + kb) * nT + tb];
+    GnPart r;
+    r.n = (in && nv > 0) ? 16.0f * (float)nv : 0.f;
+    r.mean = pr.x; r.m2 = pr.y;
     return r;
 }
 static __device__ __forceinline__ void gn_group_finish(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, GnPart first, float& mu, float& var, int Tv) {
     const int nT = (T + 31) >> 5, P = cg16 * nT;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    chan(n, mean, m2, first.n, first.mean, first.m2);
+    chan(n, mean, m2, first.n, first.mean, (first.n > 0.f) ? first.m2 : 0.f);      // (an empty partial's M2 is whatever its clamped load returned)
     for (int p0 = 64; p0 < P; p0 += 64) {
         const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0, Tv);
-        chan(n, mean, m2, q.n, q.mean, q.m2);
+        chan(n, mean, m2, q.n, q.mean, (q.n > 0.f) ? q.m2 : 0.f);
     }
     chan_step<0x111, 0xf, true>(n, mean, m2);
     chan_step<0x112, 0xf, true>(n, mean, m2);
@@ -105,11 +108,11 @@ static __device__ __forceinline__ void gnf_group_stats(const float2* __restrict_
     }
     mu = gnf_wave_sum(s1) / N;
     float d = first.mean - mu;
-    float s2 = fmaf(first.n * d, d, first.m2);      // (an empty partial: n = mean = M2 = 0 contributes 0)
+    float s2 = (first.n > 0.f) ? fmaf(first.n * d, d, first.m2) : 0.f;      // (an empty partial carries n = 0 and the finite values of a clamped load)
     for (int p0 = 64; p0 < P; p0 += 64) {
         const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0, Tv);
         d = q.mean - mu;
-        s2 += fmaf(q.n * d, d, q.m2);
+        s2 += (q.n > 0.f) ? fmaf(q.n * d, d, q.m2) : 0.f;
     }
     var = gnf_wave_sum(s2) / N;
 }
