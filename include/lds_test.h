@@ -100,6 +100,12 @@ int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, in
 /* tuning only (tools/tune_split_rules.py): bit mask of alternative tile rules of the split-GEMM launcher, 0 = the shipped rules */
 /* 0: the transformer blocks' GroupNorm runs as its own pass instead of folded into proj_in (A/B measurements and tests); default 1 */
 int lds_debug_set_gn_fold(int on);
+/* the narrow vocoder stages' residual steps: 1 (default) = one fused launch per step (csrc/voc_pair.hip), 0 = two convolution launches */
+int lds_debug_set_voc_pair(int on);
+/* one residual step of ResBlock1 at 16 / 32 channels through the fused kernel: out = (acc ? acc : 0) + c2(lrelu(c1(lrelu(x)))) + x, / div
+ * (reference models.py:186-192, 250-259); x, acc, out dev [B][C][T], weights host [C][C][K]; lengths host int32 [B] or null */
+int lds_test_voc_pair(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil,
+                      const float* acc, float div, const int32_t* lengths, float* out, int B, void* stream);
 int lds_debug_set_split_rule(int rule);
 /* plain [B,C,T] -> K8B3 -> plain: must return the input bit for bit (the three-term split is lossless) */
 int lds_test_k8b3_roundtrip(const float* x, float* out, int B, int C, int T, void* stream);

@@ -58,6 +58,22 @@ bool conv_mono_applies(const ConvArgs& a);      // one output channel, k 7: the 
 hipError_t launch_conv_mono(const ConvArgs& a, hipStream_t s);
 const char* conv_small_last_config();
 
+// voc_pair (voc_pair.hip): one residual step of the vocoder's ResBlock1 at 16 / 32 channels as one launch over plain [B][C][T] tensors:
+// out = (accum ? out : 0) + c2(lrelu(c1(lrelu(x)))) + x, divided by out_div; c1 dilated by `dil`, both k = KT, "same" zero padding;
+// frames at and beyond vlen[b] (device int32 [B], null = T) are outside the utterance: the intermediate reads as zero there and the
+// output is written as zeros.  x and out must not alias (neighbouring tiles read x's halo).
+struct VocPairArgs {
+    const float* x; float* out;
+    const float* w1; const float* b1; int Mp1;      // packed weights [KT][C/8][2][Mp][4] and packed-row biases (model.hip pack_conv)
+    const float* w2; const float* b2; int Mp2;
+    int C, KT, dil, B, T;
+    int accum; float out_div; float slope;
+    const int* vlen;
+};
+bool voc_pair_applies(int C, int KT, int dil);
+hipError_t launch_voc_pair(const VocPairArgs& a, hipStream_t s);
+const char* voc_pair_last_config();
+
 // Weight packers (host side): reference layout -> [KT][Ci][Mp]
 size_t packed_conv_elems(int Co, int Ci, int K, int* Mp_out);
 

@@ -485,6 +485,7 @@ struct DOpt {
 };
 // Batch size the launchers judge their tile / split choices at while a UNet call of this thread is running: 0 = the nominal batch (the
 // default: results do not depend on the batch split), the actual batch in latency mode (lds_unet_set_latency_mode).
+static std::atomic<int> g_voc_pair{1};     // lds_debug_set_voc_pair: 0 = the narrow vocoder stages' residual steps as two launches (A/B measurements, tests)
 static std::atomic<int> g_gn_fold{1};      // lds_debug_set_gn_fold: 0 = the transformer's GroupNorm as its own pass (A/B measurements, tests)
 // per-utterance lengths of the ragged batch a UNet call of this thread is running on (device int32 [B]; null = none): k4p.h ragged_len
 static thread_local const int* tl_lens = nullptr;
@@ -1911,6 +1912,37 @@ static int voc_mrf_dma(const lds_vocoder* v, const VocWs& w, int stage, const fl
     return LDS_OK;
 }
 
+// One residual step of ResBlock1 on a narrow stage as one launch (voc_pair.hip): out = (accum ? out : 0) + c2(lrelu(c1(lrelu(x)))) + x, / div
+static int run_voc_pair(const ConvW& W1, const ConvW& W2, const float* x, float* out, int ch, int Tl, int dil, bool accum, float div, const int* vlen, int B,
+                        hipStream_t st) {
+    VocPairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.out = out; a.w1 = W1.w; a.b1 = W1.bias; a.Mp1 = W1.Mp; a.w2 = W2.w; a.b2 = W2.bias; a.Mp2 = W2.Mp;
+    a.C = ch; a.KT = W1.K; a.dil = dil; a.B = B; a.T = Tl; a.accum = accum ? 1 : 0; a.out_div = div; a.slope = 0.1f; a.vlen = vlen;
+    const double flops = 2.0 * 2.0 * B * (double)Tl * ch * ch * W1.K;
+    const double bytes = 4.0 * B * (double)ch * Tl * (accum ? 3.0 : 2.0);
+    hipError_t e;
+    {
+        ProfScope ps(st, "voc_pair", flops, bytes);
+        e = launch_voc_pair(a, st);
+        if (ps.on) {
+            std::string cfgs(voc_pair_last_config());
+            std::string nm = "voc_pair<" + cfgs.substr(0, cfgs.find(" grid")) + ">";
+            if (g_prof_level.load(std::memory_order_relaxed) >= 2) {
+                char sh[96];
+                snprintf(sh, sizeof(sh), " Ci%d Co%d K%d+%d d%d To%d +res%s", ch, ch, W1.K, W2.K, dil, Tl, accum ? " +acc" : "");
+                nm += sh;
+            }
+            ps.rename(nm);
+        }
+    }
+    if (e != hipSuccess) return fail(LDS_EHIP, "voc_pair launch failed (%s): C %d K %d dil %d T %d", hipGetErrorString(e), ch, W1.K, dil, Tl);
+    return LDS_OK;
+}
+static bool voc_pair_ok(const lds_vocoder_cfg& c, const VocRes& rb, int m, int ch) {
+    return c.resblock == 1 && g_voc_pair.load(std::memory_order_relaxed) && voc_pair_applies(ch, rb.k, rb.dil[m]) && rb.c1[m].Mp == 32 && rb.c2[m].Mp == 32;
+}
+
 static int vocoder_forward_impl(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream, const int* lens_host);
 extern "C" int lds_vocoder_forward(lds_vocoder* v, const float* z, float* wav, void* ws, size_t ws_bytes, int B, int T, void* stream) {
     return vocoder_forward_impl(v, z, wav, ws, ws_bytes, B, T, stream, nullptr);
@@ -2012,7 +2044,9 @@ static int vocoder_forward_impl(lds_vocoder* v, const float* z, float* wav, void
                 o2.res = cur; o2.vlen = vl[i + 1];
                 if (last) { o2.accum = j > 0; o2.out_div = (j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f; }
                 float* dst = last ? xs : pp[m & 1];
-                if (c.resblock == 1) {
+                if (voc_pair_ok(c, rb, m, ch)) {
+                    LDS_TRY(run_voc_pair(rb.c1[m], rb.c2[m], cur, dst, ch, Tl, d, o2.accum != 0, o2.out_div, vl[i + 1], B, st));
+                } else if (c.resblock == 1) {
                     LDS_TRY(run_conv(rb.c1[m], s1, o1, w.ta, B, st));
                     Src s2{w.ta, ch, nullptr, 0, Tl};
                     o2.pad = (rb.k - 1) / 2; o2.act_in = ACT_LRELU; o2.slope = 0.1f;
@@ -2568,6 +2602,33 @@ extern "C" int lds_test_gn_apply_split(const float* x1, const float* x2, int C1,
     return LDS_OK;
 }
 
+extern "C" int lds_debug_set_voc_pair(int on) {
+    g_voc_pair.store(on ? 1 : 0);
+    return LDS_OK;
+}
+// One residual step of a narrow-stage ResBlock1 through the fused kernel: x dev [B][C][T], weights host [C][C][K] / [C]; acc dev or null (then
+// out = step(x)), lengths host int32 [B] or null; out dev [B][C][T] (must not alias x).
+extern "C" int lds_test_voc_pair(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil,
+                                 const float* acc, float div, const int32_t* lengths, float* out, int B, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !w1 || !w2 || !out || !voc_pair_applies(C, K, dil) || B < 1 || B > 64) return fail(LDS_EINVAL, "bad argument");
+    Owner own;
+    TmpDev tmp;
+    ConvW W1, W2;
+    if (!pack_conv(own, w1, b1, C, C, K, W1) || !pack_conv(own, w2, b2, C, C, K, W2)) return fail(LDS_ENOMEM, "upload failed");
+    int* vl = nullptr;
+    if (lengths) {
+        vl = (int*)tmp.f(64);
+        if (!vl) return fail(LDS_ENOMEM, "alloc");
+        float t4[64];
+        memcpy(t4, lengths, sizeof(int) * B);
+        HIP_TRY(launch_set_list((float*)vl, t4, B, st));
+    }
+    if (acc) HIP_TRY(hipMemcpyAsync(out, acc, sizeof(float) * (size_t)B * C * T, hipMemcpyDeviceToDevice, st));
+    LDS_TRY(run_voc_pair(W1, W2, x, out, C, T, dil, acc != nullptr, div, vl, B, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LDS_OK;
+}
 extern "C" int lds_debug_set_gn_fold(int on) {
     g_gn_fold.store(on ? 1 : 0);
     return LDS_OK;

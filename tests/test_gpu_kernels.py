@@ -222,3 +222,71 @@ def test_vocoder_resblock_step_dma(C, T, K, dil, mode, B):
     assert relmax(out.cpu().numpy(), y) < 2e-5, relmax(out.cpu().numpy(), y)
     if mode == 1:
         assert relmax(out_act.cpu().numpy(), lrelu(y)) < 2e-5
+
+
+@pytest.mark.parametrize("C,T,K,dil,B,acc,ragged", [(16, 1500, 3, 1, 2, False, False), (16, 1037, 7, 3, 1, True, False), (16, 2048, 11, 5, 2, True, True),
+                                                   (16, 130, 11, 1, 1, False, False), (32, 1000, 3, 5, 2, True, True), (32, 777, 7, 5, 1, False, False),
+                                                   (32, 1024, 7, 1, 2, True, False), (32, 1200, 11, 3, 2, False, True), (32, 40, 11, 5, 1, True, False),
+                                                   (32, 733, 11, 1, 3, True, True)])
+def test_vocoder_resblock_step_fused(C, T, K, dil, B, acc, ragged):
+    """one residual step of ResBlock1 at the vocoder's 16- / 32-channel stages as ONE launch (csrc/voc_pair.hip: c1 -> LDS -> c2, frames as the
+    MFMA rows) against the numpy oracle: several tiles per utterance, last tiles ragged, T not a multiple of 4 (the scalar-access instantiation),
+    T shorter than one tile, the running-sum epilogue, and per-utterance lengths (the intermediate is ZERO beyond an utterance's end, the output too)"""
+    _need_gpu()
+    from lds import native
+    from oracle import unet1d
+    tag = f"vp{C}.{T}.{K}.{dil}"
+    x = U(tag + ".x", (B, C, T), -2, 2)
+    w1 = U(tag + ".w1", (C, C, K)) / np.float32(np.sqrt(C * K))
+    w2 = U(tag + ".w2", (C, C, K)) / np.float32(np.sqrt(C * K))
+    b1, b2 = U(tag + ".b1", (C,), -0.3, 0.3), U(tag + ".b2", (C,), -0.3, 0.3)
+    a = U(tag + ".acc", (B, C, T), -1, 1)
+    lens = np.array([T if b == 0 else max(1, (T * (3 + b)) // (5 + b)) for b in range(B)], dtype=np.int32) if ragged else None
+
+    def lrelu(v):
+        return np.where(v >= 0, v, v * np.float32(0.1)).astype(np.float32)
+    ref = np.zeros_like(x)
+    for b in range(B):
+        n = int(lens[b]) if ragged else T
+        xb = x[b:b + 1, :, :n].copy()
+        xt = unet1d.conv1d(lrelu(xb), w1, b1, pad=(K * dil - dil) // 2, dil=dil)
+        y = (unet1d.conv1d(lrelu(xt), w2, b2, pad=(K - 1) // 2) + xb).astype(np.float32)
+        if acc:
+            y = ((a[b:b + 1, :, :n] + y) / np.float32(3.0)).astype(np.float32)
+        ref[b, :, :n] = y[0]
+    xin = x.copy()
+    if ragged:
+        for b in range(B):
+            xin[b, :, lens[b]:] = 0          # (the producer of a ragged batch writes zeros beyond each utterance)
+    out = torch.full((B, C, T), float("nan"), dtype=torch.float32, device="cuda")
+    dx, dacc = dev(xin), dev(a)
+    native.check(native.lib().lds_test_voc_pair(ct.c_void_p(dx.data_ptr()), ct.c_void_p(w1.ctypes.data), ct.c_void_p(b1.ctypes.data), ct.c_void_p(w2.ctypes.data),
+                                                ct.c_void_p(b2.ctypes.data), C, T, K, dil, ct.c_void_p(dacc.data_ptr() if acc else None),
+                                                ct.c_float(3.0 if acc else 1.0), ct.c_void_p(lens.ctypes.data if ragged else None),
+                                                ct.c_void_p(out.data_ptr()), B, ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    if ragged:
+        for b in range(B):
+            assert not got[b, :, lens[b]:].any(), "frames beyond an utterance's length must be written as zeros"
+    assert relmax(got, ref) < 2e-5, relmax(got, ref)
+
+
+def test_vocoder_fused_steps_equal_two_launch_steps():
+    """the whole decode with the narrow stages' residual steps fused equals the decode with two launches per step (same summation order at
+    16 channels: bit-equal there; 32 channels used conv_gemm's order: 1e-6)"""
+    _need_gpu()
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights, native
+    h = arch.SYNTHETIC_VOCODER_H
+    state = init_weights.init_state(arch.generator_param_shapes(h), 0)
+    voc = Hifi_VAEGAN(None, device="cuda", h=h, state=state)
+    mel = torch.from_numpy(U("vf.mel", (2, 37, 80), -4, 1)).cuda()
+    try:
+        native.check(native.lib().lds_debug_set_voc_pair(0))
+        two = voc(mel).cpu().numpy()
+    finally:
+        native.check(native.lib().lds_debug_set_voc_pair(1))
+    one = voc(mel).cpu().numpy()
+    assert np.isfinite(one).all() and relmax(one, two) < 2e-6, relmax(one, two)
