@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) voc_pair_kernel(const VocPairArgs p, i
                     const int jb = j0 + 16 * half;               // (wave-uniform)
                     if constexpr (vec) {                         // (T and N are multiples of 4: a quad is wholly inside or outside the row)
                         int o = rowb + t0 + jb;
-                        if (!inner) o = (t0 + jb + 4 * l4 < T) ? o : rowb;      // (blocks past the row's end: any valid address, the value is not stored)
+                        if (!inner) o = (t0 + jb + 4 * l4 < T) ? o : rowb - 4 * l4;      // (blocks past the row's end: the row's first quad, whose value is not stored)
                         r_[half] = *reinterpret_cast<const f32x4*>(xrow + o);
                         a_[half] = *reinterpret_cast<const f32x4*>(arow + o);
                     } else {

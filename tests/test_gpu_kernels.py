@@ -227,7 +227,8 @@ def test_vocoder_resblock_step_dma(C, T, K, dil, mode, B):
 @pytest.mark.parametrize("C,T,K,dil,B,acc,ragged", [(16, 1500, 3, 1, 2, False, False), (16, 1037, 7, 3, 1, True, False), (16, 2048, 11, 5, 2, True, True),
                                                    (16, 130, 11, 1, 1, False, False), (32, 1000, 3, 5, 2, True, True), (32, 777, 7, 5, 1, False, False),
                                                    (32, 1024, 7, 1, 2, True, False), (32, 1200, 11, 3, 2, False, True), (32, 40, 11, 5, 1, True, False),
-                                                   (32, 733, 11, 1, 3, True, True)])
+                                                   (32, 733, 11, 1, 3, True, True), (16, 4, 3, 1, 1, False, False), (32, 8, 11, 5, 2, True, True),
+                                                   (16, 5, 7, 3, 1, False, False), (32, 252, 3, 1, 1, False, False), (16, 508, 3, 5, 2, True, False)])
 def test_vocoder_resblock_step_fused(C, T, K, dil, B, acc, ragged):
     """one residual step of ResBlock1 at the vocoder's 16- / 32-channel stages as ONE launch (csrc/voc_pair.hip: c1 -> LDS -> c2, frames as the
     MFMA rows) against the numpy oracle: several tiles per utterance, last tiles ragged, T not a multiple of 4 (the scalar-access instantiation),

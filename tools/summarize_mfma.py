@@ -29,7 +29,7 @@ def main():
     out = {}
     for k, c in agg.items():
         b, w, m = c["SQ_BUSY_CYCLES"], c["SQ_WAVE_CYCLES"], c["SQ_VALU_MFMA_BUSY_CYCLES"]
-        if not b or not w or not k.startswith(("conv_", "attention", "gn_", "lm_")):
+        if not b or not w or not k.startswith(("conv_", "attention", "gn_", "lm_", "voc_")):
             continue
         out[k] = {"launches": cnt[k], "mfma_busy_frac": m / (b * 32.0), "mfma_busy_cycles_per_launch": m / cnt[k],
                   "wait_any_frac": c["SQ_WAIT_ANY"] / w, "wait_inst_frac": c["SQ_WAIT_INST_ANY"] / w, "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / w}
