@@ -363,31 +363,14 @@ struct Bf3Kernel {
     }
 
     // LayerNorm over the input channels folded into the epilogue (conv_dma.hip ln_columns): per output column combine the
-    // producer's per-32-channel (mean, M2) partials in a fixed order (Chan)
+    // producer's per-32-channel (mean, M2) partials in a fixed order (gn_chan.h ln_column_stats)
     __device__ __forceinline__ void ln_columns() {
-        constexpr int CH = 8;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = t0 + wn * TN * 32 + j * 32 + c;
             const bool ok = n < p.To;
             const float2* src = p.ln_part + (long long)b * p.ln_np * p.Tsrc + (ok ? n : 0);
-            float mean = 0.f, m2 = 0.f, cnt = 0.f;
-            for (int q0 = 0; q0 < p.ln_np; q0 += CH) {
-                float2 pr[CH];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) pr[e] = src[(long long)((q0 + e < p.ln_np) ? q0 + e : q0) * p.Tsrc];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    if (q0 + e < p.ln_np) {
-                        const float d = pr[e].x - mean, nn = cnt + 32.f;
-                        mean += d * (32.f * __builtin_amdgcn_rcpf(nn));
-                        m2 += pr[e].y + d * d * (cnt * 32.f * __builtin_amdgcn_rcpf(nn));
-                        cnt = nn;
-                    }
-                }
-            }
-            lmu[j] = mean;
-            lrs[j] = ok ? 1.0f / sqrtf(m2 / cnt + p.ln_eps) : 0.f;
+            ln_column_stats(src, p.Tsrc, p.ln_np, p.ln_eps, ok, lmu[j], lrs[j]);      // (gn_chan.h: two plain sums in a fixed order)
         }
     }
 

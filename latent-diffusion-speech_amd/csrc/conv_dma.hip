@@ -273,33 +273,15 @@ struct DmaKernel {
     }
 
     // LayerNorm over the input channels (reference attention.py:83,102,118), folded into the epilogue: per output column
-    // combine the producer's per-32-channel (mean, M2) partials in a fixed order (Chan).  Called right after the first
-    // tiles' DMAs are issued; the partials are fetched eight at a time so the loads overlap instead of forming a chain
-    // of dependent round trips.
+    // combine the producer's per-32-channel (mean, M2) partials in a fixed order (gn_chan.h ln_column_stats).  Called right
+    // after the first tiles' DMAs are issued; all partials of a column are requested at once (no chain of dependent round trips).
     __device__ __forceinline__ void ln_columns() {
-        constexpr int CH = 16;      // (all partials of the widest level, 512 channels, in one round trip)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = t0 + wn * TN * 32 + j * 32 + c;
             const bool ok = n < p.To;
             const float2* src = p.ln_part + (long long)b * p.ln_np * p.Tsrc + (ok ? n : 0);
-            float mean = 0.f, m2 = 0.f, cnt = 0.f;
-            for (int q0 = 0; q0 < p.ln_np; q0 += CH) {
-                float2 pr[CH];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) pr[e] = src[(long long)((q0 + e < p.ln_np) ? q0 + e : q0) * p.Tsrc];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    if (q0 + e < p.ln_np) {
-                        const float d = pr[e].x - mean, nn = cnt + 32.f;
-                        mean += d * (32.f * __builtin_amdgcn_rcpf(nn));     // nn = 32 * k: the quotient 1/k rounds the same in rcp
-                        m2 += pr[e].y + d * d * (cnt * 32.f * __builtin_amdgcn_rcpf(nn));
-                        cnt = nn;
-                    }
-                }
-            }
-            lmu[j] = mean;
-            lrs[j] = ok ? 1.0f / sqrtf(m2 / cnt + p.ln_eps) : 0.f;
+            ln_column_stats(src, p.Tsrc, p.ln_np, p.ln_eps, ok, lmu[j], lrs[j]);      // (gn_chan.h: two plain sums in a fixed order)
         }
     }
 

@@ -117,4 +117,37 @@ static __device__ __forceinline__ void gnf_group_stats(const float2* __restrict_
     var = gnf_wave_sum(s2) / N;
 }
 
+// LayerNorm statistics of one output column from the producer's np partials (mean, M2) over 32 channels each (conv_dma.hip / conv_bf3.hip
+// ln_columns; reference attention.py:83,102,118).  Equal counts make the combination two plain sums in a fixed order,
+//   mean = sum(mean_i) / np,   var = (sum(M2_i) + 32 sum((mean_i - mean)^2)) / (32 np),
+// ~4 vector instructions per partial instead of the 10 of a running Chan update with its two reciprocals.
+// Up to 16 partials (512 channels) stay in registers between the two sums; more are read twice.
+static __device__ __forceinline__ void ln_column_stats(const float2* src, long long stride, int np, float eps, bool ok, float& mu, float& rs) {
+    constexpr int CH = 16;
+    const float cnt = 32.f * (float)np;
+    float s1 = 0.f, s2 = 0.f;
+    if (np <= CH) {
+        float2 pr[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) pr[e] = src[(long long)(e < np ? e : 0) * stride];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s1 += (e < np) ? pr[e].x : 0.f;
+        mu = s1 / (float)np;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const float d = pr[e].x - mu;
+            s2 += (e < np) ? fmaf(32.f * d, d, pr[e].y) : 0.f;
+        }
+    } else {
+        for (int e = 0; e < np; ++e) s1 += src[(long long)e * stride].x;
+        mu = s1 / (float)np;
+        for (int e = 0; e < np; ++e) {
+            const float2 q = src[(long long)e * stride];
+            const float d = q.x - mu;
+            s2 += fmaf(32.f * d, d, q.y);
+        }
+    }
+    rs = ok ? 1.0f / sqrtf(s2 / cnt + eps) : 0.f;
+}
+
 }  // namespace lds
