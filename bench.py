@@ -98,15 +98,18 @@ def lib_fingerprint():
     return _sha256(os.path.join(ROOT, "latent-diffusion-speech_amd", "lds", "liblds.so"))
 
 
-def _newest_profile_json(suffix):
+def _newest_profile_json(suffix, key=None):
+    """newest profiles/*<suffix> (by name: rNN_...) that holds `key` under "kernels" -- a round commits several summaries with one suffix
+    (the sampler's and the vocoder's), and only one of them knows a given kernel"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
-    if not files:
-        return None, None
-    try:
-        return json.load(open(files[-1])), os.path.basename(files[-1])
-    except Exception:
-        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if key is None or key in d.get("kernels", {}):
+            return d, os.path.basename(f)
+    return None, None
 
 
 def _pmc_key(kernel_name):
@@ -130,9 +133,9 @@ def pmc_lookup(kernel_name, suffix, field=None):
     passes summarised by tools/summarize_pmc.py / summarize_mfma.py and stamped by tools/stamp_profile.py).  These are NOT measured in
     this run: the provenance says which file and which commit it was taken on, and `stale` is true when the summary carries no stamp
     or a source file of the kernel's family has changed since."""
-    d, fname = _newest_profile_json(suffix)
     key = _pmc_key(kernel_name)
-    if not d or key is None or key not in d.get("kernels", {}):
+    d, fname = _newest_profile_json(suffix, key) if key is not None else (None, None)
+    if not d:
         return None, None
     v = d["kernels"][key]
     prov = {"file": "profiles/" + fname, "commit": d.get("commit")}
