@@ -102,6 +102,9 @@ int lds_test_gn_apply_split(const float* x1, const float* x2, int C1, int C2, in
 int lds_debug_set_gn_fold(int on);
 /* the narrow vocoder stages' residual steps: 1 (default) = one fused launch per step (csrc/voc_pair.hip), 0 = two convolution launches */
 int lds_debug_set_voc_pair(int on);
+/* experiment: 1 = a convolution's weights are read (one dword per 64-byte line) by a small launch immediately before the convolution's own:
+ * the upper bound of what a weight prefetcher could give (tools/touch_weights_probe.py) */
+int lds_debug_set_touch_weights(int on);
 /* one residual step of ResBlock1 at 16 / 32 channels through the fused kernel: out = (acc ? acc : 0) + c2(lrelu(c1(lrelu(x)))) + x, / div
  * (reference models.py:186-192, 250-259); x, acc, out dev [B][C][T], weights host [C][C][K]; lengths host int32 [B] or null */
 int lds_test_voc_pair(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int C, int T, int K, int dil,

@@ -236,6 +236,7 @@ enum {
 hipError_t launch_ew(int op, float* out, const float* a, const float* b, const float* c, const float* d,
                      float c0, float c1, float c2, float c3, float c4, long long n, hipStream_t s);
 hipError_t launch_fill(float* p, float v, long long n, hipStream_t s);
+hipError_t launch_touch_lines(const float* p, long long bytes, hipStream_t s);      // experiment: lds_debug_set_touch_weights
 struct FloatList64 { float f[64]; };
 // dst[0..n) = host[0..n), n <= 64, carried in the kernel arguments (the host array is read during the call only)
 hipError_t launch_set_list(float* dst, const float* host, int n, hipStream_t s);

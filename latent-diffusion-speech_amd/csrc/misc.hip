@@ -115,6 +115,21 @@ hipError_t launch_ew(int op, float* out, const float* a, const float* b, const f
 __global__ void __launch_bounds__(256) fill_kernel(float* p, float v, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
 }
+// experiment (lds_debug_set_touch_weights): read one dword of every 64-byte line of a buffer, so that the next launch finds it in the
+// memory-side cache / the touching XCDs' L2s -- the upper bound of what a weight prefetcher could give a launch
+__global__ void __launch_bounds__(256) touch_lines_kernel(const float* p, long long n_lines, float* sink) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < n_lines) v = p[i * 16];
+    if (v == 1.2345678e-30f && sink) sink[0] = v;      // (keeps the load)
+}
+hipError_t launch_touch_lines(const float* p, long long bytes, hipStream_t s) {
+    const long long n_lines = bytes / 64;
+    if (n_lines <= 0) return hipSuccess;
+    hipLaunchKernelGGL(touch_lines_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, s, p, n_lines, (float*)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(float* p, float v, long long n, hipStream_t s) {
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -485,6 +485,7 @@ struct DOpt {
 };
 // Batch size the launchers judge their tile / split choices at while a UNet call of this thread is running: 0 = the nominal batch (the
 // default: results do not depend on the batch split), the actual batch in latency mode (lds_unet_set_latency_mode).
+static std::atomic<int> g_touch_w{0};       // lds_debug_set_touch_weights: experiment, off in the product path
 static std::atomic<int> g_voc_pair{1};     // lds_debug_set_voc_pair: 0 = the narrow vocoder stages' residual steps as two launches (A/B measurements, tests)
 static std::atomic<int> g_gn_fold{1};      // lds_debug_set_gn_fold: 0 = the transformer's GroupNorm as its own pass (A/B measurements, tests)
 // per-utterance lengths of the ragged batch a UNet call of this thread is running on (device int32 [B]; null = none): k4p.h ragged_len
@@ -583,6 +584,7 @@ static int run_dconv(const ConvW& W, const float* x1, int C1, const float* x2, i
     const double flops = 2.0 * B * (double)a.To * (double)W.Co * (double)W.Ci * (double)W.K;
     const double bytes = 4.0 * ((double)B * W.Ci * Tsrc + (double)W.K * W.Ci * W.Co + (double)B * a.Cout * a.To * (o.res ? 2.0 : 1.0));
     hipError_t e;
+    if (g_touch_w.load(std::memory_order_relaxed)) HIP_TRY(launch_touch_lines(W.w, 4ll * W.K * W.Ci * W.Mp, st));
     {
         ProfScope ps(st, "conv_dma", flops, bytes, true);
         e = launch_conv_dma(a, o.cfg, st);
@@ -657,6 +659,10 @@ static int run_dconv_pair(const ConvW& W3, const float* h, const ConvW& W1, cons
     const double bytes = 4.0 * ((double)B * (W3.Ci + W1.Ci) * T + (double)W3.Co * (3.0 * W3.Ci + W1.Ci) + (double)B * a1.Cout * a1.To);
     if (!conv_dma_pair_applies(a3, a1)) return 1;
     hipError_t e;
+    if (g_touch_w.load(std::memory_order_relaxed)) {
+        HIP_TRY(launch_touch_lines(W3.w, 4ll * W3.K * W3.Ci * W3.Mp, st));
+        HIP_TRY(launch_touch_lines(W1.w, 4ll * W1.K * W1.Ci * W1.Mp, st));
+    }
     {
         ProfScope ps(st, "conv_dma", flops, bytes, true);
         e = launch_conv_dma_pair(a3, a1, st);
@@ -2602,6 +2608,10 @@ extern "C" int lds_test_gn_apply_split(const float* x1, const float* x2, int C1,
     return LDS_OK;
 }
 
+extern "C" int lds_debug_set_touch_weights(int on) {
+    g_touch_w.store(on ? 1 : 0);
+    return LDS_OK;
+}
 extern "C" int lds_debug_set_voc_pair(int on) {
     g_voc_pair.store(on ? 1 : 0);
     return LDS_OK;

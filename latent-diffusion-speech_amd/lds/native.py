@@ -58,7 +58,7 @@ TEST_EXPORTS = [
     "lds_test_ln_chain_k4p", "lds_test_attention_k4p", "lds_test_conv_transpose", "lds_test_voc_step", "lds_test_dconv_bf3",
     "lds_bench_dconv_bf3", "lds_test_k8b3_roundtrip", "lds_test_gn_apply_bf3", "lds_test_dconv_split", "lds_bench_dconv_split",
     "lds_test_split_roundtrip", "lds_test_gn_apply_split", "lds_debug_set_split_rule", "lds_test_attention_f16math",
-    "lds_test_attention_latency", "lds_debug_set_gn_fold", "lds_debug_set_voc_pair", "lds_test_voc_pair", "lds_test_gn_fold_k4p", "lds_bench_dconv_alt", "lds_debug_fill_u32", "lds_debug_trace",
+    "lds_test_attention_latency", "lds_debug_set_gn_fold", "lds_debug_set_voc_pair", "lds_debug_set_touch_weights", "lds_test_voc_pair", "lds_test_gn_fold_k4p", "lds_bench_dconv_alt", "lds_debug_fill_u32", "lds_debug_trace",
     "lds_debug_trace_count", "lds_debug_trace_get", "lds_debug_unet_plan", "lds_test_gn_fold_split", "lds_test_cluster_join", "lds_test_lm_sample"]
 
 
