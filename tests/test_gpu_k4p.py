@@ -255,8 +255,9 @@ def test_groupnorm_fold_k4p(Cm, T, B, tile_batch, record_margin):
     record_margin(relmax(out.cpu().numpy(), ref), 2e-5)
 
 
-@pytest.mark.parametrize("C,Co,T,B", [(256, 768, 64, 2), (384, 384, 100, 1), (512, 1536, 37, 2)])
+@pytest.mark.parametrize("C,Co,T,B", [(256, 768, 64, 2), (384, 384, 100, 1), (512, 1536, 37, 2), (1024, 256, 70, 1), (128, 128, 40, 1)])
 def test_layernorm_chain_k4p(C, Co, T, B):
+    """... 1024 channels: 32 partials per column, the two-read form of gn_chan.h ln_column_stats (the UNet's widest level has 16)"""
     from lds import native
     from oracle import unet1d
     x = U(f"lnc{C}.x", (B, C, T), -2, 2)
