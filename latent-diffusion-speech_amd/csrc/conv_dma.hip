@@ -320,7 +320,7 @@ struct DmaKernel {
             if (g < G_) {
                 float mu, var;
                 gnf_group_stats(p.gnf_part, b, p.Ci, p.Tsrc, gsz >> 4, g, lane, e ? gp1 : gp0, mu, var, ragged_len(p.lens, b, p.lvl_in, p.Tsrc));
-                rs = 1.0f / sqrtf(var + p.gnf_eps); rm = rs * mu;
+                rs = __builtin_amdgcn_rsqf(var + p.gnf_eps); rm = rs * mu;
             }
             if (lane == 0) { tail[g] = rs; tail[8 + g] = rm; }
         }

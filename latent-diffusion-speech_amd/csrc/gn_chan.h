@@ -100,13 +100,13 @@ static __device__ __forceinline__ float gnf_wave_sum(float v) {      // total in
 static __device__ __forceinline__ void gnf_group_stats(const float2* __restrict__ gp, int b, int C, int T, int cg16, int g, int lane, GnPart first, float& mu,
                                                        float& var, int Tv) {
     const int nT = (T + 31) >> 5, P = cg16 * nT;
-    const float N = 16.0f * (float)cg16 * (float)Tv;
+    const float rN = __builtin_amdgcn_rcpf(16.0f * (float)cg16 * (float)Tv);      // (1 ulp; the IEEE division is ~25 dependent instructions in front of the first MFMA)
     float s1 = first.n * first.mean;
     for (int p0 = 64; p0 < P; p0 += 64) {
         const GnPart q = gn_part_load(gp, b, C, T, cg16, g, lane, p0, Tv);
         s1 = fmaf(q.n, q.mean, s1);
     }
-    mu = gnf_wave_sum(s1) / N;
+    mu = gnf_wave_sum(s1) * rN;
     float d = first.mean - mu;
     float s2 = (first.n > 0.f) ? fmaf(first.n * d, d, first.m2) : 0.f;      // (an empty partial carries n = 0 and the finite values of a clamped load)
     for (int p0 = 64; p0 < P; p0 += 64) {
@@ -114,7 +114,7 @@ static __device__ __forceinline__ void gnf_group_stats(const float2* __restrict_
         d = q.mean - mu;
         s2 += (q.n > 0.f) ? fmaf(q.n * d, d, q.m2) : 0.f;
     }
-    var = gnf_wave_sum(s2) / N;
+    var = gnf_wave_sum(s2) * rN;
 }
 
 // LayerNorm statistics of one output column from the producer's np partials (mean, M2) over 32 channels each (conv_dma.hip / conv_bf3.hip
@@ -132,7 +132,8 @@ static __device__ __forceinline__ void ln_column_stats(const float2* src, long l
         for (int e = 0; e < CH; ++e) pr[e] = src[(long long)(e < np ? e : 0) * stride];
 #pragma unroll
         for (int e = 0; e < CH; ++e) s1 += (e < np) ? pr[e].x : 0.f;
-        mu = s1 / (float)np;
+        mu = s1 * __builtin_amdgcn_rcpf((float)np);      // (v_rcp_f32 / v_rsq_f32, 1 ulp: the IEEE division and square-root sequences are ~25 dependent
+                                                         //  instructions each, in front of the launch's first MFMA)
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
             const float d = pr[e].x - mu;
@@ -140,14 +141,14 @@ static __device__ __forceinline__ void ln_column_stats(const float2* src, long l
         }
     } else {
         for (int e = 0; e < np; ++e) s1 += src[(long long)e * stride].x;
-        mu = s1 / (float)np;
+        mu = s1 * __builtin_amdgcn_rcpf((float)np);
         for (int e = 0; e < np; ++e) {
             const float2 q = src[(long long)e * stride];
             const float d = q.x - mu;
             s2 += fmaf(32.f * d, d, q.y);
         }
     }
-    rs = ok ? 1.0f / sqrtf(s2 / cnt + eps) : 0.f;
+    rs = ok ? __builtin_amdgcn_rsqf(fmaf(s2, __builtin_amdgcn_rcpf(cnt), eps)) : 0.f;
 }
 
 }  // namespace lds

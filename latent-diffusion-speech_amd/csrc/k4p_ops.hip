@@ -228,10 +228,13 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
     const int g = (q * 8) / (C / groups);
     const int nT = (T + 31) >> 5, P = cg16 * nT, nk1 = C1 >> 4;
     const float inv_nT = 1.0f / (float)nT;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int p0 = 0; p0 < P; p0 += 64) {              // <= 2 rounds for every shape of the UNet
+    // two plain sums in a fixed order (gn_chan.h gnf_wave_sum): mean = sum(n_i mean_i) / N, var = sum(M2_i + n_i (mean_i - mean)^2) / N with
+    // N = 16 cg16 Tv known outright -- a dependent chain of 2 x 6 additions where the Chan tree had 6 steps of a dozen operations with a
+    // reciprocal each, on the critical path of a launch that is latency-bound (DESIGN.md sections 3.10, 14.10).  The partials of the first
+    // two rounds (<= 128: every shape of the UNet at T <= 1024) stay in registers between the sums; further rounds are read twice.
+    auto part = [&](int p0, float& nb, float& mb, float& qb) {
         const int pi = p0 + lane;
-        float nb = 0.f, mb = 0.f, qb = 0.f;
+        nb = 0.f; mb = 0.f; qb = 0.f;
         if (pi < P) {
             const int kk = (int)(((float)pi + 0.5f) * inv_nT), tb = pi - kk * nT, kb = g * cg16 + kk;      // pi / nT without the integer-division sequence
             const int nv = (Tv - tb * 32 < 32) ? Tv - tb * 32 : 32;
@@ -240,18 +243,28 @@ __global__ void __launch_bounds__(256) gn_stream_kernel(const float* __restrict_
                 nb = 16.0f * (float)nv; mb = pr.x; qb = pr.y;
             }
         }
-        chan(n, mean, m2, nb, mb, qb);
+    };
+    float n0, m0, q0, n1 = 0.f, m1 = 0.f, q1 = 0.f;
+    part(0, n0, m0, q0);
+    if (P > 64) part(64, n1, m1, q1);
+    float s1 = fmaf(n1, m1, n0 * m0);
+    for (int p0 = 128; p0 < P; p0 += 64) {
+        float nb, mb, qb;
+        part(p0, nb, mb, qb);
+        s1 = fmaf(nb, mb, s1);
     }
-    chan_step<0x111, 0xf, true>(n, mean, m2);
-    chan_step<0x112, 0xf, true>(n, mean, m2);
-    chan_step<0x114, 0xf, true>(n, mean, m2);
-    chan_step<0x118, 0xf, true>(n, mean, m2);
-    chan_step<0x142, 0xa, false>(n, mean, m2);
-    chan_step<0x143, 0xc, false>(n, mean, m2);
-    const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mean), 63));
-    const float var = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m2), 63)) /
-                      __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n), 63));
-    const float rstd = 1.0f / sqrtf(var + eps);
+    const float rN = __builtin_amdgcn_rcpf(16.0f * (float)cg16 * (float)Tv);
+    const float mu = gnf_wave_sum(s1) * rN;
+    float d0 = m0 - mu, d1 = m1 - mu;
+    float s2 = fmaf(n0 * d0, d0, q0) + fmaf(n1 * d1, d1, q1);      // (an empty partial carries n = 0, mean = 0, M2 = 0)
+    for (int p0 = 128; p0 < P; p0 += 64) {
+        float nb, mb, qb;
+        part(p0, nb, mb, qb);
+        const float d = mb - mu;
+        s2 += fmaf(nb * d, d, qb);
+    }
+    const float var = gnf_wave_sum(s2) * rN;
+    const float rstd = __builtin_amdgcn_rsqf(var + eps);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
