@@ -222,3 +222,40 @@ def test_mode_switch_refused_while_a_call_is_in_progress():
     assert refused and "in progress" in refused[0], "no switch was refused while the sampler call was enqueueing"
     nat.set_latency_mode(True)
     nat.set_latency_mode(False)
+
+
+@pytest.mark.gpu
+def test_vocoder_decode_repeatable():
+    """the decode with the fused residual steps of the narrow stages (csrc/voc_pair.hip: persistent workgroups, two LDS tiles handed from
+    phase to phase and from tile to tile behind workgroup barriers) is a function of its inputs: five decodes of one batch, bit for bit,
+    with a second stream streaming HBM beside the last three"""
+    import threading
+    import numpy as np
+    import torch
+    from encoder.hifi_vaegan.hifi_vaegan import Hifi_VAEGAN
+    from lds import arch, init_weights
+    h = arch.SYNTHETIC_VOCODER_H
+    voc = Hifi_VAEGAN(None, device="cuda", h=h, state=init_weights.init_state(arch.generator_param_shapes(h), 0))
+    mel = torch.from_numpy(init_weights.uniform("det.voc.mel", (3, 70, 80), 9, -4, 1)).cuda()
+    ref = voc(mel).cpu().numpy()
+    assert np.isfinite(ref).all()
+    for _ in range(2):
+        assert np.array_equal(voc(mel).cpu().numpy(), ref)
+    stop = threading.Event()
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+
+    def load():
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                big.add_(1.0)
+                side.synchronize()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        for _ in range(3):
+            assert np.array_equal(voc(mel).cpu().numpy(), ref)
+    finally:
+        stop.set()
+        th.join()
