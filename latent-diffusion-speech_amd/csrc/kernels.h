@@ -235,6 +235,8 @@ enum {
 };
 hipError_t launch_ew(int op, float* out, const float* a, const float* b, const float* c, const float* d,
                      float c0, float c1, float c2, float c3, float c4, long long n, hipStream_t s);
+hipError_t launch_dpm_step(float* x, const float* eps, float* m0, const float* m1, float sigma, float alpha, int second, float c4, float c5, float c6,
+                           float c7, long long n, hipStream_t s);      // EW_X0 + EW_AXPBY / EW_DPM2 in one pass
 hipError_t launch_fill(float* p, float v, long long n, hipStream_t s);
 hipError_t launch_touch_lines(const float* p, long long bytes, hipStream_t s);      // experiment: lds_debug_set_touch_weights
 struct FloatList64 { float f[64]; };

@@ -112,6 +112,27 @@ hipError_t launch_ew(int op, float* out, const float* a, const float* b, const f
     return hipGetLastError();
 }
 
+// One DPM-Solver++(2M) step in one pass (the EW_X0 launch and the EW_AXPBY / EW_DPM2 launch behind it: the same expressions in the same
+// order, the data prediction handed over in a register instead of through memory): m0 = (x - sigma eps) / alpha, then
+// x = c4 x - c5 m0 [- c6 (c7 (m0 - m1))]
+__global__ void __launch_bounds__(256) dpm_step_kernel(float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ m0, const float* __restrict__ m1,
+                                                       float sigma, float alpha, int second, float c4, float c5, float c6, float c7, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float xi = x[i];
+        const float bi = (xi - sigma * eps[i]) / alpha;
+        m0[i] = bi;
+        x[i] = second ? c4 * xi - c5 * bi - c6 * (c7 * (bi - m1[i])) : c4 * xi - c5 * bi;
+    }
+}
+hipError_t launch_dpm_step(float* x, const float* eps, float* m0, const float* m1, float sigma, float alpha, int second, float c4, float c5, float c6,
+                           float c7, long long n, hipStream_t s) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ProfScope ps(s, "ew", 0.0, 4.0 * (second ? 5.0 : 4.0) * (double)n);
+    hipLaunchKernelGGL(dpm_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, eps, m0, m1, sigma, alpha, second, c4, c5, c6, c7, n);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* p, float v, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
 }

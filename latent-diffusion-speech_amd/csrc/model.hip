@@ -1584,9 +1584,7 @@ static int sampler_run_impl(lds_unet* u, int method, int n_rows, const float* ta
             const float* r = table + (size_t)i * S;
             LDS_TRY(model(x, r[0]));
             float* tmp = m1; m1 = m0; m0 = tmp;
-            HIP_TRY(launch_ew(EW_X0, m0, x, s.eps, nullptr, nullptr, r[1], r[2], 0, 0, 0, n, st));
-            if (r[3] < 1.5f) HIP_TRY(launch_ew(EW_AXPBY, x, x, m0, nullptr, nullptr, r[4], r[5], 0, 0, 0, n, st));
-            else HIP_TRY(launch_ew(EW_DPM2, x, x, m0, m1, nullptr, r[4], r[5], r[6], r[7], 0, n, st));
+            HIP_TRY(launch_dpm_step(x, s.eps, m0, m1, r[1], r[2], r[3] < 1.5f ? 0 : 1, r[4], r[5], r[6], r[7], n, st));      // (x0 and the update: one launch)
         }
     } else if (method == LDS_METHOD_UNIPC) {
         // row 0: {t_in, sigma, alpha}; rows s>=1: {t_in, sigma_s, alpha_s, order, sigma_s/sigma_{s-1}, alpha_s*h_phi_1,
