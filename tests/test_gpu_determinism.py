@@ -259,3 +259,21 @@ def test_vocoder_decode_repeatable():
     finally:
         stop.set()
         th.join()
+
+
+def test_experiment_switches_do_not_change_results():
+    """the experiment switch of include/lds_test.h that only adds launches -- a convolution's weights read by a small launch before it
+    (lds_debug_set_touch_weights) -- leaves a UNet forward bit for bit as it was, and restores cleanly"""
+    from diffusion.unit2mel import Unit2Mel
+    from lds import init_weights, native
+    m = Unit2Mel(1280, 323, 80).to("cuda").eval()
+    unet = m.decoder.denoise_fn
+    x = torch.from_numpy(init_weights.uniform("sw.x", (2, 336, 96), 33, -2, 2)).cuda()
+    t = torch.from_numpy(np.array([250.25, 40.5], dtype=np.float32)).cuda()
+    ref = unet(x, t).sample.clone()
+    try:
+        native.check(native.lib().lds_debug_set_touch_weights(1))
+        assert torch.equal(unet(x, t).sample, ref)
+    finally:
+        native.check(native.lib().lds_debug_set_touch_weights(0))
+    assert torch.equal(unet(x, t).sample, ref)
