@@ -13,7 +13,8 @@
 // MFMA: v_mfma_f32_16x16x4_f32 (exact fp32) with FRAMES as the M rows and output channels as the N columns, so that a lane's four
 // accumulators are four consecutive frames of one channel: the LDS tile of phase 1 and every global access of phase 2's epilogue are
 // 16 bytes per lane.  A wave keeps the weights of BOTH convolutions for its 16 output channels in registers (2 x KT*C/4) for the
-// lifetime of the persistent workgroup (32 channels at k 11: one convolution's at a time, PairCfg::RELOAD); one ds_read_b32 per MFMA feeds the frame operand (rows padded to 16 mod 32 floats).
+// lifetime of the persistent workgroup (32 channels at k 11: one convolution's at a time, PairCfg::RELOAD); one ds_read_b32 per MFMA
+// feeds the frame operand (rows padded to 16 mod 32 floats).
 // N is chosen so that both phases are exactly 16 (C = 32) or 32 (C = 16) blocks of 16 frames: every wave runs four two-chain
 // iterations per phase.
 // Per-element summation order: k = (tap, input channel) ascending, one accumulator chain -- independent of batch and tiling, and the
@@ -42,8 +43,9 @@ struct PairCfg {
     static constexpr int WPH = ((NH - 16 + 31) / 32) * 32 + 16;          // ds_read_b32 (lanes 0-15 / 16-31 / ...) fall on disjoint bank groups
     static constexpr int NA = KT * C / 4;                // MFMAs (= weight registers) per 16 x 16 tile and convolution
     static constexpr int NCH = (C * W4 + 255) / 256;     // staged chunks per thread
-    // Register budget (two waves per SIMD = 256 registers): both convolutions' weights stay resident when 2 NA <= 88; 32 channels at
-    // k 7 / 11 (2 x 56, 2 x 88) keep one convolution's at a time and request the other's from L2 behind the last matrix pass of a phase.
+    // Register budget (two waves per SIMD = 256 registers): both convolutions' weights stay resident up to 2 x 56 (32 channels, k 7);
+    // 32 channels at k 11 (2 x 88) keeps one convolution's at a time and requests the other's from L2 behind the last matrix pass of a
+    // phase (~12 % slower than resident would be).
     static constexpr bool RELOAD = NA >= 88;
     static constexpr bool LATE = C == 32 && KT >= 7;     // the next tile's window is requested behind the LAST matrix pass (its 40 registers do not fit beside the weights)
     static constexpr bool HOLD = C == 16 || KT == 3;     // the window chunks' (row, LDS offset) pairs kept in registers across tiles
