@@ -13,7 +13,7 @@
 // MFMA: v_mfma_f32_16x16x4_f32 (exact fp32) with FRAMES as the M rows and output channels as the N columns, so that a lane's four
 // accumulators are four consecutive frames of one channel: the LDS tile of phase 1 and every global access of phase 2's epilogue are
 // 16 bytes per lane.  A wave keeps the weights of BOTH convolutions for its 16 output channels in registers (2 x KT*C/4) for the
-// lifetime of the persistent workgroup (32 channels at k 11: one convolution's at a time, PairCfg::RELOAD); one ds_read_b32 per MFMA
+// lifetime of the persistent workgroup (32 channels at k 11: at one workgroup per CU, PairCfg::OCC); one ds_read_b32 per MFMA
 // feeds the frame operand (rows padded to 16 mod 32 floats).
 // N is chosen so that both phases are exactly 16 (C = 32) or 32 (C = 16) blocks of 16 frames: every wave runs four two-chain
 // iterations per phase.
@@ -43,13 +43,15 @@ struct PairCfg {
     static constexpr int WPH = ((NH - 16 + 31) / 32) * 32 + 16;          // ds_read_b32 (lanes 0-15 / 16-31 / ...) fall on disjoint bank groups
     static constexpr int NA = KT * C / 4;                // MFMAs (= weight registers) per 16 x 16 tile and convolution
     static constexpr int NCH = (C * W4 + 255) / 256;     // staged chunks per thread
-    // Register budget (two waves per SIMD = 256 registers): both convolutions' weights stay resident up to 2 x 56 (32 channels, k 7);
-    // 32 channels at k 11 (2 x 88) keeps one convolution's at a time and requests the other's from L2 behind the last matrix pass of a
-    // phase (~12 % slower than resident would be).
-    static constexpr bool RELOAD = NA >= 88;
-    static constexpr bool LATE = C == 32 && KT >= 7;     // the next tile's window is requested behind the LAST matrix pass (its 40 registers do not fit beside the weights)
-    static constexpr bool HOLD = C == 16 || KT == 3;     // the window chunks' (row, LDS offset) pairs kept in registers across tiles
-    static constexpr bool PIPE = C == 16 || KT == 3;     // residual quads requested one iteration ahead into a second register set (where 32 more registers fit)
+    // Register budget: at two workgroups per CU (256 registers per wave) both convolutions' weights stay resident up to 2 x 56 (32 channels,
+    // k 7).  32 channels at k 11 (2 x 88) runs ONE workgroup per CU with everything resident (350 registers): 850-890 us per launch, against
+    // 917-936 us at two per CU with one convolution's weights at a time refetched from L2 behind the last matrix pass of a phase (RELOAD,
+    // kept for the scalar-access instantiation), DESIGN.md section 14.8.
+    static constexpr int OCC = (C == 32 && KT == 11) ? 1 : 2;      // workgroups per CU
+    static constexpr bool RELOAD = false;
+    static constexpr bool LATE = C == 32 && KT == 7;     // the next tile's window is requested behind the LAST matrix pass (its 40 registers do not fit beside the weights)
+    static constexpr bool HOLD = C == 16 || KT == 3 || OCC == 1;     // the window chunks' (row, LDS offset) pairs kept in registers across tiles
+    static constexpr bool PIPE = C == 16 || KT == 3 || OCC == 1;     // residual quads requested one iteration ahead into a second register set (where 32 more registers fit)
     static constexpr size_t LDS_BYTES = (size_t)C * (WPX + WPH) * sizeof(float);
     static_assert(C == 16 || C == 32, "tail widths");
     static_assert(N % 4 == 0 && N > 0, "tiles start on 16-byte boundaries");
@@ -92,7 +94,7 @@ __device__ __forceinline__ void pair_mma_pass(const float* lds, unsigned boff, c
 }
 
 template <int C, int KT, int DIL, bool VEC>
-__global__ void __launch_bounds__(256, 2) voc_pair_kernel(const VocPairArgs p, int n_tiles) {
+__global__ void __launch_bounds__(256, (PairCfg<C, KT, DIL>::OCC)) voc_pair_kernel(const VocPairArgs p, int n_tiles) {
     using Cfg = PairCfg<C, KT, DIL>;
     constexpr int N = Cfg::N, NH = Cfg::NH, H1 = Cfg::H1, H0 = Cfg::H0, W4 = Cfg::W4, WPX = Cfg::WPX, WPH = Cfg::WPH, NA = Cfg::NA, NCH = Cfg::NCH;
     constexpr int NCT = Cfg::NCT, C4 = C / 4;
@@ -110,9 +112,9 @@ __global__ void __launch_bounds__(256, 2) voc_pair_kernel(const VocPairArgs p, i
     const int nt = (T + N - 1) / N;
 
     // ---- weights of this wave's 16 output channels: B operand of MFMA (tap, kb) = W[co = 16 cot + (l & 15)][ci = 4 kb + (l >> 4)][tap] ----
-    // RELOAD: one convolution's weights at a time, the other's requested from L2 behind the last matrix pass of a phase.  (Keeping three taps
-    // of each resident and streaming the other eight behind them -- so that a refill has MFMAs to arrive behind -- was tried: the compiler's
-    // register allocation of that form spills ~100 registers.)
+    // RELOAD (the scalar-access instantiations of the wide shapes): one convolution's weights at a time, the other's requested from L2 behind
+    // the last matrix pass of a phase.  (Keeping three taps of each resident and streaming the other eight behind them -- so that a refill has
+    // MFMAs to arrive behind -- was tried: the compiler's register allocation of that form spills ~100 registers.)
     float w1[NA], w2[RELOAD ? 1 : NA];
     auto load_w = [&](const float* wp, float* dst) {
         // element (tap, ci = 4 kb + l4, co) of [tap][ci / 8][ci % 2][Mp = 32][(ci % 8) / 2]: a compile-time part (tap, kb) in the buffer load's scalar
@@ -356,7 +358,7 @@ static hipError_t launch_pair_cfg(const VocPairArgs& a, hipStream_t s) {
     }
     const long long n_tiles = (long long)a.B * ((a.T + Cfg::N - 1) / Cfg::N);
     if (n_tiles > 0x7fffffffll) return hipErrorInvalidValue;
-    const int grid = n_tiles < 512 ? (int)n_tiles : 512;      // persistent: two workgroups per CU stride over the tiles, weights loaded once
+    const int grid = n_tiles < 256 * Cfg::OCC ? (int)n_tiles : 256 * Cfg::OCC;      // persistent: two workgroups per CU stride over the tiles, weights loaded once
     snprintf(g_pcfg, sizeof(g_pcfg), "C%d KT%d D%d N%d grid %d", C, KT, DIL, Cfg::N, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, s, a, (int)n_tiles);
     return hipGetLastError();
