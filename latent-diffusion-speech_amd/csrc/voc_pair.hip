@@ -15,8 +15,8 @@
 // 16 bytes per lane.  A wave keeps the weights of BOTH convolutions for its 16 output channels in registers (2 x KT*C/4) for the
 // lifetime of the persistent workgroup (32 channels at k 11: at one workgroup per CU, PairCfg::OCC); one ds_read_b32 per MFMA
 // feeds the frame operand (rows padded to 16 mod 32 floats).
-// N is chosen so that both phases are exactly 16 (C = 32) or 32 (C = 16) blocks of 16 frames: every wave runs four two-chain
-// iterations per phase.
+// N is chosen so that both phases are exactly 16 / 32 / 64 blocks of 16 frames (8 per wave, 16 for the shape that runs one workgroup per
+// CU): every wave runs four (eight) two-chain iterations per phase.
 // Per-element summation order: k = (tap, input channel) ascending, one accumulator chain -- independent of batch and tiling, and the
 // order conv_small uses.
 #include "kernels.h"
@@ -24,6 +24,7 @@
 #include <stdio.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace lds {
 
@@ -33,7 +34,10 @@ template <int C, int KT, int DIL>
 struct PairCfg {
     static constexpr int NCT = C / 16;                   // output-channel tiles of 16
     static constexpr int NFS = 4 / NCT;                  // waves per channel tile
-    static constexpr int NBLK = 8 * NFS;                 // 16-frame blocks per phase (8 per wave)
+    static constexpr int OCC = (C == 32 && KT == 11) ? 1 : 2;      // workgroups per CU (see RELOAD below)
+    static constexpr int BPW = OCC == 1 ? 16 : 8;        // 16-frame blocks per wave and phase: the lone workgroup of a CU takes a tile twice as long
+    static constexpr int IT = BPW / 2;                   // two-chain iterations per wave and phase
+    static constexpr int NBLK = BPW * NFS;               // 16-frame blocks per phase
     static constexpr int NH = 16 * NBLK;                 // frames of the intermediate tile
     static constexpr int H1 = (KT - 1) / 2, H0 = H1 * DIL;
     static constexpr int N = (NH - 2 * H1) & ~3;         // output frames per tile (tiles start on 16-byte boundaries)
@@ -47,7 +51,6 @@ struct PairCfg {
     // k 7).  32 channels at k 11 (2 x 88) runs ONE workgroup per CU with everything resident (350 registers): 850-890 us per launch, against
     // 917-936 us at two per CU with one convolution's weights at a time refetched from L2 behind the last matrix pass of a phase (RELOAD,
     // kept for the scalar-access instantiation), DESIGN.md section 14.8.
-    static constexpr int OCC = (C == 32 && KT == 11) ? 1 : 2;      // workgroups per CU
     static constexpr bool RELOAD = false;
     static constexpr bool LATE = C == 32 && KT == 7;     // the next tile's window is requested behind the LAST matrix pass (its 40 registers do not fit beside the weights)
     static constexpr bool HOLD = C == 16 || KT == 3 || OCC == 1;     // the window chunks' (row, LDS offset) pairs kept in registers across tiles
@@ -63,6 +66,9 @@ struct PairCfg {
 // formed ONCE per pass and hidden from the optimiser, so that every read of the pass is base + immediate (no address arithmetic per tap:
 // VALU instructions are paid in matrix time); operands are double-buffered per tap (the next tap's reads are in
 // flight behind the current tap's MFMAs), which keeps the operands in flight at two taps' worth.
+template <class F, int... I>
+__device__ __forceinline__ void pair_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+
 template <int C4, int KT, int TSTEP, int ROW>
 __device__ __forceinline__ void pair_mma_pass(const float* lds, unsigned boff, const float* w, f32x4& d0, f32x4& d1) {
     unsigned bk[C4];
@@ -223,8 +229,8 @@ __global__ void __launch_bounds__(256, (PairCfg<C, KT, DIL>::OCC)) voc_pair_kern
             const int u0 = t0 - H1;                                 // frame of h column 0
             const bool inner = u0 >= 0 && u0 + NH <= Tv;            // (wave-uniform) no column of the tile is outside the utterance
 #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                const int j0 = 16 * (8 * fsl + 2 * it);
+            for (int it = 0; it < Cfg::IT; ++it) {
+                const int j0 = 16 * (Cfg::BPW * fsl + 2 * it);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
                 pair_mma_pass<C4, KT, DIL, WPX>(smem, x_boff + (unsigned)((off + j0) * 4), w1, d0, d1);
                 // D[row = frame 4 (l >> 4) + r][col = channel l & 15]
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(256, (PairCfg<C, KT, DIL>::OCC)) voc_pair_kern
             const bool inner = t0 + NH <= Tv;                    // (wave-uniform) every frame of the tile's blocks is inside the utterance (and the row)
             // residual (and running-sum) quads of both chains of iteration `it`: requested one matrix pass before they are consumed
             auto request = [&](int it, f32x4* r_, f32x4* a_) {
-                const int j0 = 16 * (8 * fsl + 2 * it);
+                const int j0 = 16 * (Cfg::BPW * fsl + 2 * it);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int jb = j0 + 16 * half;               // (wave-uniform)
@@ -278,11 +284,11 @@ __global__ void __launch_bounds__(256, (PairCfg<C, KT, DIL>::OCC)) voc_pair_kern
             };
             // one iteration: matrix pass, the NEXT iteration's request into the other register set, then this iteration's epilogue
             auto step = [&](int it, auto last_c, const f32x4* rc, const f32x4* ac, f32x4* rn, f32x4* an) {      // (rc / ac: this iteration's quads; rn / an: where the request goes)
-                const int j0 = 16 * (8 * fsl + 2 * it);
+                const int j0 = 16 * (Cfg::BPW * fsl + 2 * it);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (!PIPE) request(it, rn, an);      // (one register set: requested before this iteration's own pass)
                 pair_mma_pass<C4, KT, 1, WPH>(smem, h_boff + (unsigned)(j0 * 4), RELOAD ? w1 : w2, d0, d1);      // (the last block's taps stay inside the row: j0 + 31 + KT - 1 < WPH)
-                if constexpr (PIPE) request(it < 3 ? it + 1 : 3, rn, an);      // (the last iteration repeats its own request: the count of loads in flight stays fixed)
+                if constexpr (PIPE) request(it < Cfg::IT - 1 ? it + 1 : Cfg::IT - 1, rn, an);      // (the last iteration repeats its own request: the count of loads in flight stays fixed)
                 if constexpr (!PIPE) { rc = rn; ac = an; }
                 if constexpr (decltype(last_c)::value) {                // (the tile's last iteration, known at compile time: nothing here is loop-carried)
                     if constexpr (RELOAD) load_w(p.w1, w1);    // c1's weights for the next tile
@@ -326,14 +332,17 @@ __global__ void __launch_bounds__(256, (PairCfg<C, KT, DIL>::OCC)) voc_pair_kern
             f32x4 rA[2], aA[2], rB[2], aB[2];      // two register sets, alternating: no copy of a load still in flight
             if constexpr (PIPE) {
                 request(0, rA, aA);
-                step(0, std::false_type{}, rA, aA, rB, aB);      // (straight-line: a loop header would merge two register assignments of the
-                step(1, std::false_type{}, rB, aB, rA, aA);      //  sets in flight and make the compiler wait for fresh loads there)
-                step(2, std::false_type{}, rA, aA, rB, aB);
-                step(3, std::true_type{}, rB, aB, rA, aA);
+                // straight-line code (a loop header would merge two register assignments of the sets in flight and make the compiler wait for
+                // fresh loads there): iterations 0 .. IT-1, the register sets alternating
+                pair_static_for([&](auto ic) {
+                    constexpr int it = decltype(ic)::value;
+                    if constexpr (it & 1) step(it, std::bool_constant<it == Cfg::IT - 1>{}, rB, aB, rA, aA);
+                    else step(it, std::bool_constant<it == Cfg::IT - 1>{}, rA, aA, rB, aB);
+                }, std::make_integer_sequence<int, Cfg::IT>{});
             } else {
 #pragma unroll 1
-                for (int it = 0; it < 3; ++it) step(it, std::false_type{}, rA, aA, rA, aA);
-                step(3, std::true_type{}, rA, aA, rA, aA);
+                for (int it = 0; it < Cfg::IT - 1; ++it) step(it, std::false_type{}, rA, aA, rA, aA);
+                step(Cfg::IT - 1, std::true_type{}, rA, aA, rA, aA);
             }
             if constexpr (Cfg::LATE) {
                 if (has_next) commit();            // (behind the last epilogue: the other resident workgroup's matrix work covers the wait)
@@ -349,7 +358,7 @@ template <int C, int KT, int DIL>
 static hipError_t launch_pair_cfg(const VocPairArgs& a, hipStream_t s) {
     using Cfg = PairCfg<C, KT, DIL>;
     auto kern = (a.T & 3) ? voc_pair_kernel<C, KT, DIL, false> : voc_pair_kernel<C, KT, DIL, true>;
-    static_assert(Cfg::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static_assert(Cfg::LDS_BYTES <= (size_t)(160 / Cfg::OCC) * 1024, "OCC workgroups per CU");
     if (Cfg::LDS_BYTES > 48 * 1024) {
         static std::atomic<unsigned long long> attr_done{0}, attr_done2{0};
         hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(voc_pair_kernel<C, KT, DIL, true>), attr_done);
